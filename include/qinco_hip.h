@@ -1,0 +1,120 @@
+/*
+ * qinco_hip.h -- C ABI of libqinco_hip.so, the MI355X (gfx950) QINCo / QINCo2 encode-decode engine.
+ *
+ * The reference (facebookresearch/Qinco) is pure Python over ATen; this ABI is what a Python (ctypes),
+ * C++ or any-FFI host binds in place of the reference's model object for the encode/decode path:
+ *
+ *   qinco_create        <-  QINCo(cfg) + load_state_dict + QINCoInferenceWrapper.build()
+ *                           (qinco/qinco_tasks.py:302-309, qinco/model/qinco_inference.py:285-294)
+ *   qinco_set_beam      <-  the CLI override of A / B over the checkpoint's values (qinco/utils.py:166-172)
+ *   qinco_encode[_host] <-  model(x, step="encode")   (qinco_inference.py:272-279, 239-254, 156-224, 78-140)
+ *   qinco_decode[_host] <-  model(codes, step="decode") (qinco_inference.py:280-281, 66-75)
+ *   qinco_destroy       <-  del model
+ *
+ * Conventions: plain pointers and sizes only.  Codes cross the boundary as (n, M) row-major (the reference
+ * returns (M, n); its on-disk format and every consumer use (n, M): search_tasks.py:115).  All entry points
+ * return 0 on success or a negative qinco_status; qinco_last_error() gives the message of the last failure on
+ * the calling thread.  A handle is bound to the HIP device that was current at qinco_create; it is not
+ * thread-safe (one handle per host thread / stream), different handles are independent.
+ */
+#ifndef QINCO_HIP_H
+#define QINCO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define QINCO_API __attribute__((visibility("default")))
+#else
+#define QINCO_API
+#endif
+
+typedef struct qinco_handle_s* qinco_handle;
+
+typedef enum {
+  QINCO_OK = 0,
+  QINCO_ERR_INVALID = -1,      /* bad argument / unsupported hyper-parameters (reference: assert / ValueError) */
+  QINCO_ERR_HIP = -2,          /* HIP runtime failure */
+  QINCO_ERR_UNSUPPORTED = -3,  /* (D, De, Dh) has no compiled kernel instance */
+  QINCO_ERR_RANGE = -4         /* a code >= K was passed to decode (reference: index error) */
+} qinco_status;
+
+/* element types of the x / codes buffers */
+enum { QINCO_X_F32 = 0, QINCO_X_U8 = 1 };
+enum { QINCO_CODE_I64 = 0, QINCO_CODE_I32 = 1, QINCO_CODE_U8 = 2 };
+/* flags: operate in the model's normalised space, i.e. the .encode(x_norm) / .decode(codes) methods of
+ * QINCoInferenceWrapper (qinco_inference.py:330-350) instead of forward()'s (x - mean) / std and * std + mean */
+enum { QINCO_FLAG_NORMALISED = 1 };
+
+/* Hyper-parameters: checkpoint["parameters"] + checkpoint["data_dim"]  (qinco/utils.py:100-137). */
+typedef struct {
+  int32_t D;            /* data dimension (cfg._D) */
+  int32_t De;           /* cfg.de, or D when de is None (QINCo1) */
+  int32_t Dh;           /* cfg.dh */
+  int32_t L;            /* residual blocks per step */
+  int32_t M;            /* number of steps (cfg._M_ivf; no IVF step in this version) */
+  int32_t K;            /* codebook size of every step */
+  int32_t A;            /* candidates pre-selected per beam (0 = all K, QINCo1) */
+  int32_t B;            /* beam size */
+  int32_t qinco1_mode;  /* 1: res_codeword_coeff = 0 (qinco_inference.py:29) */
+  int32_t reserved;
+  int64_t max_batch;    /* vectors processed per internal pass (scratch is sized for it) */
+} qinco_desc;
+
+/* Host pointers to contiguous fp32 tensors in the reference state_dict layout (qinco_base.py:229-260, 432-445).
+ * Arrays are indexed by step m = 0..M-1; entry 0 of the per-MLP arrays is ignored (step 0 is codebook only). */
+typedef struct {
+  const float* data_mean;           /* (D) */
+  float data_std;                   /* () must be > 0 (qinco_base.py:526) */
+  const float* const* codebook;     /* [M] -> (K, D)   steps.m.codebook.weight */
+  const float* const* sub_codebook; /* [M] -> (K, D)   steps.m.substep.codebook.weight; NULL entries / NULL if A == 0 */
+  const float* const* in_proj;      /* [M] -> (De, D)  steps.m.in_proj.weight;  NULL if De == D */
+  const float* const* out_proj;     /* [M] -> (D, De)  steps.m.out_proj.weight; NULL if De == D */
+  const float* const* cat_w;        /* [M] -> (De, De + D) steps.m.concat.mlp.weight (cat order: z then xhat) */
+  const float* const* cat_b;        /* [M] -> (De)     steps.m.concat.mlp.bias */
+  const float* const* up;           /* [M*L] -> (Dh, De) steps.m.residual_blocks.l.up_proj.weight   at [m*L + l] */
+  const float* const* down;         /* [M*L] -> (De, Dh) steps.m.residual_blocks.l.down_proj.weight at [m*L + l] */
+} qinco_weights;
+
+QINCO_API int qinco_create(const qinco_desc* desc, const qinco_weights* weights, qinco_handle* out);
+QINCO_API int qinco_destroy(qinco_handle h);
+
+/* Change the search width.  A must be 0 iff the model was created with A == 0 (utils.py:169-172); 0 < A <= K. */
+QINCO_API int qinco_set_beam(qinco_handle h, int32_t A, int32_t B);
+
+/* Device-pointer entry points: x / codes / out are device (or device-accessible) buffers; work is enqueued on
+ * `stream` (a hipStream_t; NULL = default stream) and NOT synchronised.  x rows are `x_row_stride_bytes`
+ * apart (0 = tightly packed).  codes_out is (n, M) of `code_dtype`; xhat_out (nullable) receives the
+ * NORMALISED reconstruction (n, D) that QINCoInferenceWrapper.encode returns next to the codes. */
+QINCO_API int qinco_encode(qinco_handle h, const void* x, int x_dtype, int64_t x_row_stride_bytes, int64_t n,
+                 void* codes_out, int code_dtype, float* xhat_out, int flags, void* stream);
+QINCO_API int qinco_decode(qinco_handle h, const void* codes, int code_dtype, int64_t n, float* out, int flags,
+                 void* stream);
+
+/* Host-pointer convenience forms (stage through device buffers owned by the handle; synchronous). */
+QINCO_API int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int64_t x_row_stride_bytes, int64_t n,
+                      void* codes_out, int code_dtype, float* xhat_out, int flags);
+QINCO_API int qinco_decode_host(qinco_handle h, const void* codes, int code_dtype, int64_t n, float* out, int flags);
+
+/* Roofline instrumentation: when enabled, every launch of the fused-MLP kernel is bracketed by HIP events on
+ * its own stream.  qinco_profile_read synchronises, returns the totals since the last read and resets them. */
+QINCO_API int qinco_profile_enable(qinco_handle h, int enable);
+QINCO_API int qinco_profile_read(qinco_handle h, double* mlp_ms, int64_t* mlp_launches, double* mlp_flops);
+
+/* Algorithmic FLOPs of one vector's encode / decode at the handle's current A, B. */
+QINCO_API double qinco_flops_per_vector_encode(qinco_handle h);
+QINCO_API double qinco_flops_per_vector_decode(qinco_handle h);
+
+/* 1 if a fused-MLP kernel instance exists for (D, De, Dh). */
+QINCO_API int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh);
+
+QINCO_API const char* qinco_last_error(void);
+QINCO_API const char* qinco_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QINCO_HIP_H */

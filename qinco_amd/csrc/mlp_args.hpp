@@ -1,0 +1,51 @@
+// Argument block and weight-stream geometry shared by the fused-MLP kernel (device) and the packer (host).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace qinco {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// Fragment (1 KiB = 64 lanes x float4) counts of each section of the packed per-step weight stream.
+// Every section is padded to a multiple of the ring depth P so ring slots are compile-time constants.
+struct StreamDims {
+  int NDB, NEB, NHB;
+  bool PROJ;
+  int T_IN, T_BIAS, T_CAT, T_UP, T_DOWN, T_OUT;
+  constexpr long total(int L) const { return (long)T_IN + T_BIAS + T_CAT + (long)L * (T_UP + T_DOWN) + T_OUT; }
+};
+
+constexpr StreamDims stream_dims(int D, int DE, int DH, int P) {
+  StreamDims s{};
+  s.NDB = D / 32;
+  s.NEB = DE / 32;
+  s.NHB = DH / 32;
+  s.PROJ = (D != DE);
+  s.T_IN = s.PROJ ? round_up(s.NEB * s.NDB * 4, P) : 0;
+  s.T_BIAS = round_up(s.NEB * 4, P);
+  s.T_CAT = round_up(s.NEB * (s.NEB + s.NDB) * 4, P);
+  s.T_UP = round_up(s.NHB * s.NEB * 4, P);
+  s.T_DOWN = round_up(s.NEB * s.NHB * 4, P);
+  s.T_OUT = s.PROJ ? round_up(s.NDB * s.NEB * 4, P) : 0;
+  return s;
+}
+
+struct MlpArgs {
+  const f32x4* wstream;   // packed weight stream of this step (+P fragments of tail padding)
+  int L;                  // number of residual FFN blocks
+  const float* codebook;  // (K, D) main codebook of this step
+  const int* cand_ids;    // (R) codebook row per MLP row, or nullptr -> id = row % A
+  int A;                  // candidates per (vector, beam) group
+  int F;                  // beams per vector (groups per x row)
+  const float* xhat;      // (R/A, D) current reconstruction per group
+  const float* x;         // (R/A/F, D) normalised target, or nullptr (decode: no distances)
+  long R;                 // rows
+  float* cand_out;        // (R, D): f(c,xhat)+xhat
+  float* dist_out;        // (R) or nullptr
+  int add_c;              // 1: + c (QINCo2), 0: qinco1_mode (res_codeword_coeff = 0)
+};
+
+}  // namespace qinco

@@ -1,0 +1,637 @@
+// libqinco_hip.so -- C ABI (include/qinco_hip.h) over the gfx950 kernels.
+// Host side: weight packing into the kernel's stream order, scratch management, the per-step launch
+// sequence of encode (qinco_inference.py:239-254 + :156-224 / :78-140) and decode (:66-75).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qinco_hip.h"
+#include "aux_kernels.hpp"
+#include "mlp_args.hpp"
+#include "mlp_launch.hpp"
+
+using namespace qinco;
+
+// ---------------------------------------------------------------------------------------------
+// per-shape launchers (shapes.def)
+// ---------------------------------------------------------------------------------------------
+#define QINCO_SHAPE(D, DE, DH) \
+  extern "C" hipError_t qinco_mlp_launch_##D##_##DE##_##DH(const qinco::MlpArgs*, hipStream_t);
+#include "shapes.def"
+#undef QINCO_SHAPE
+
+namespace qinco {
+mlp_launch_fn find_mlp_launcher(int D, int De, int Dh) {
+#define QINCO_SHAPE(d, de, dh) \
+  if (D == d && De == de && Dh == dh) return &qinco_mlp_launch_##d##_##de##_##dh;
+#include "shapes.def"
+#undef QINCO_SHAPE
+  return nullptr;
+}
+}  // namespace qinco
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return fail(QINCO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+struct qinco_handle_s {
+  qinco_desc d{};
+  int device = 0;
+  int A = 0, B = 1;  // active search widths
+  mlp_launch_fn launch = nullptr;
+  StreamDims sd{};
+
+  float* mean = nullptr;
+  float std_ = 1.f;
+  std::vector<float*> codebook, sub_codebook, cnorm, sub_cnorm;
+  std::vector<f32x4*> wstream;
+  int* kvals = nullptr;
+  int* err_flag = nullptr;
+
+  // scratch (sized for d.max_batch, A, B)
+  int64_t cap_n = 0;
+  int cap_A = -1, cap_B = -1;
+  float* xn = nullptr;
+  float* xhat[2] = {nullptr, nullptr};
+  int* hist[2] = {nullptr, nullptr};
+  int* top_ids = nullptr;
+  int* codes_t = nullptr;
+  float* cand = nullptr;
+  float* dist = nullptr;
+
+  // host-path staging
+  void* stage_x = nullptr;
+  size_t stage_x_bytes = 0;
+  void* stage_codes = nullptr;
+  size_t stage_codes_bytes = 0;
+  float* stage_out = nullptr;
+  size_t stage_out_bytes = 0;
+
+  // profiling
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double prof_flops = 0.0;
+
+  std::vector<void*> owned;  // every device allocation, for destroy
+};
+
+static double mlp_flops_per_row(const qinco_desc& d) {
+  // R_mlp = [De != D] 4 D De + 2 (De + D) De + 4 L De Dh
+  double f = 2.0 * (d.De + d.D) * d.De + 4.0 * d.L * (double)d.De * d.Dh;
+  if (d.De != d.D) f += 4.0 * d.D * d.De;
+  return f;
+}
+
+template <class T>
+static int dev_alloc(qinco_handle_s* h, T** p, size_t count) {
+  void* q = nullptr;
+  HIP_TRY(hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16));
+  h->owned.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return 0;
+}
+
+static void dev_free(qinco_handle_s* h, void* p) {
+  if (!p) return;
+  for (auto& q : h->owned)
+    if (q == p) { q = nullptr; break; }
+  (void)hipFree(p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: reference Linear weight W (O x I, row-major; y = W x) -> stream of 1 KiB fragments.
+// Fragment (ob, ib, q): lane l, component e = W[ob*32 + (l&31)][ib*32 + 8q + 4(l>>5) + e], i.e. the A
+// operands of the 4 MFMAs k-steps r = 4q..4q+3 whose B operand is register r of input block ib.
+// ---------------------------------------------------------------------------------------------
+static void put_frag(std::vector<float>& s, const float* W, int I, int ob, int ib, int q) {
+  size_t base = s.size();
+  s.resize(base + 256);
+  for (int l = 0; l < 64; ++l)
+    for (int e = 0; e < 4; ++e)
+      s[base + l * 4 + e] = W[(size_t)(ob * 32 + (l & 31)) * I + ib * 32 + 8 * q + 4 * (l >> 5) + e];
+}
+
+static void pad_to(std::vector<float>& s, size_t frags_from, int T) {
+  size_t want = frags_from + (size_t)T * 256;
+  if (s.size() > want) abort();
+  s.resize(want, 0.f);
+}
+
+static void pack_kouter(std::vector<float>& s, const float* W, int O, int I, int T) {
+  size_t start = s.size();
+  for (int ib = 0; ib < I / 32; ++ib)
+    for (int q = 0; q < 4; ++q)
+      for (int ob = 0; ob < O / 32; ++ob) put_frag(s, W, I, ob, ib, q);
+  pad_to(s, start, T);
+}
+
+static void pack_obouter(std::vector<float>& s, const float* W, int O, int I, int T) {
+  size_t start = s.size();
+  for (int ob = 0; ob < O / 32; ++ob)
+    for (int ib = 0; ib < I / 32; ++ib)
+      for (int q = 0; q < 4; ++q) put_frag(s, W, I, ob, ib, q);
+  pad_to(s, start, T);
+}
+
+static void pack_bias(std::vector<float>& s, const float* b, int O, int T) {
+  size_t start = s.size();
+  for (int ob = 0; ob < O / 32; ++ob)
+    for (int q = 0; q < 4; ++q) {
+      size_t base = s.size();
+      s.resize(base + 256);
+      for (int l = 0; l < 64; ++l)
+        for (int e = 0; e < 4; ++e) s[base + l * 4 + e] = b[ob * 32 + 8 * q + 4 * (l >> 5) + e];
+    }
+  pad_to(s, start, T);
+}
+
+static int upload(qinco_handle_s* h, float** dst, const float* src, size_t count) {
+  int rc = dev_alloc(h, dst, count);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(*dst, src, count * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int upload_with_norms(qinco_handle_s* h, const float* cb, int K, int D, float** d_cb, float** d_norm) {
+  int rc = upload(h, d_cb, cb, (size_t)K * D);
+  if (rc) return rc;
+  std::vector<float> nrm(K);
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    for (int j = 0; j < D; ++j) s = fmaf(cb[(size_t)k * D + j], cb[(size_t)k * D + j], s);
+    nrm[k] = s;
+  }
+  return upload(h, d_norm, nrm.data(), K);
+}
+
+// ---------------------------------------------------------------------------------------------
+// scratch
+// ---------------------------------------------------------------------------------------------
+static int ensure_scratch(qinco_handle_s* h) {
+  const qinco_desc& d = h->d;
+  if (h->cap_n == d.max_batch && h->cap_A == h->A && h->cap_B == h->B) return 0;
+  void* old[] = {h->xn, h->xhat[0], h->xhat[1], h->hist[0], h->hist[1], h->top_ids, h->codes_t, h->cand, h->dist};
+  HIP_TRY(hipDeviceSynchronize());
+  for (void* p : old) dev_free(h, p);
+  h->xn = h->xhat[0] = h->xhat[1] = h->cand = h->dist = nullptr;
+  h->hist[0] = h->hist[1] = h->top_ids = h->codes_t = nullptr;
+  h->cap_n = 0;
+  const size_t n = (size_t)d.max_batch;
+  const size_t Bm = (size_t)(h->B < d.K ? h->B : d.K);   // widest beam (beam_0 = min(B, K))
+  const size_t Ae = (size_t)(h->A > 0 ? h->A : d.K);     // candidates per beam
+  int rc = 0;
+  if ((rc = dev_alloc(h, &h->xn, n * d.D))) return rc;
+  for (int i = 0; i < 2; ++i) {
+    if ((rc = dev_alloc(h, &h->xhat[i], n * Bm * d.D))) return rc;
+    if ((rc = dev_alloc(h, &h->hist[i], n * Bm * d.M))) return rc;
+  }
+  if ((rc = dev_alloc(h, &h->top_ids, n * Bm * (Ae > Bm ? Ae : Bm)))) return rc;
+  if ((rc = dev_alloc(h, &h->codes_t, n * d.M))) return rc;
+  if ((rc = dev_alloc(h, &h->cand, n * Bm * Ae * d.D))) return rc;
+  if ((rc = dev_alloc(h, &h->dist, n * Bm * Ae))) return rc;
+  h->cap_n = d.max_batch;
+  h->cap_A = h->A;
+  h->cap_B = h->B;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// create / destroy
+// ---------------------------------------------------------------------------------------------
+extern "C" int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh) {
+  return find_mlp_launcher(D, De, Dh) != nullptr;
+}
+
+extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinco_handle* out) {
+  if (!desc || !w || !out) return fail(QINCO_ERR_INVALID, "qinco_create: null argument");
+  const qinco_desc& d = *desc;
+  if (d.D <= 0 || d.De <= 0 || d.Dh <= 0 || d.M <= 0 || d.K <= 0 || d.L < 0 || d.max_batch <= 0)
+    return fail(QINCO_ERR_INVALID, "qinco_create: non-positive hyper-parameter");
+  if (d.D % 32 || d.De % 32 || d.Dh % 32)
+    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: D, De, Dh must be multiples of 32 (got %d, %d, %d)", d.D, d.De, d.Dh);
+  if (d.K > 1024) return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: K=%d > 1024 not supported", d.K);
+  if (d.A < 0 || d.A > d.K || d.B < 1) return fail(QINCO_ERR_INVALID, "qinco_create: need 0 <= A <= K and B >= 1");
+  if (!(w->data_std > 0.f)) return fail(QINCO_ERR_INVALID, "qinco_create: data_std must be > 0 (qinco_base.py:526)");
+  mlp_launch_fn fn = find_mlp_launcher(d.D, d.De, d.Dh);
+  if (!fn && d.M > 1)
+    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: no fused-MLP kernel instance for (D=%d, De=%d, Dh=%d); add it to csrc/shapes.def",
+                d.D, d.De, d.Dh);
+  if (!w->data_mean || !w->codebook) return fail(QINCO_ERR_INVALID, "qinco_create: missing data_mean / codebook");
+  if (d.M > 1 && (!w->cat_w || !w->cat_b || (d.L > 0 && (!w->up || !w->down))))
+    return fail(QINCO_ERR_INVALID, "qinco_create: missing MLP weights");
+  if (d.De != d.D && d.M > 1 && (!w->in_proj || !w->out_proj))
+    return fail(QINCO_ERR_INVALID, "qinco_create: De != D requires in_proj / out_proj");
+  if (d.A > 0 && d.M > 1 && !w->sub_codebook)
+    return fail(QINCO_ERR_INVALID, "qinco_create: A > 0 requires the substep codebooks");
+
+  qinco_handle_s* h = new qinco_handle_s();
+  h->d = d;
+  h->A = d.A;
+  h->B = d.B;
+  h->launch = fn;
+  h->std_ = w->data_std;
+  h->sd = stream_dims(d.D, d.De, d.Dh, kRing);
+  int rc = 0;
+  auto bail = [&](int code) {
+    qinco_destroy(h);
+    return code;
+  };
+  if (hipGetDevice(&h->device) != hipSuccess) return bail(fail(QINCO_ERR_HIP, "hipGetDevice failed (no HIP device?)"));
+  if ((rc = upload(h, &h->mean, w->data_mean, d.D))) return bail(rc);
+
+  h->codebook.assign(d.M, nullptr);
+  h->sub_codebook.assign(d.M, nullptr);
+  h->cnorm.assign(d.M, nullptr);
+  h->sub_cnorm.assign(d.M, nullptr);
+  h->wstream.assign(d.M, nullptr);
+  std::vector<int> kv(d.M, d.K);
+  if ((rc = dev_alloc(h, &h->kvals, d.M))) return bail(rc);
+  if (hipMemcpy(h->kvals, kv.data(), d.M * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+    return bail(fail(QINCO_ERR_HIP, "hipMemcpy(kvals) failed"));
+  if ((rc = dev_alloc(h, &h->err_flag, 1))) return bail(rc);
+  if (hipMemset(h->err_flag, 0, sizeof(int)) != hipSuccess) return bail(fail(QINCO_ERR_HIP, "hipMemset failed"));
+
+  for (int m = 0; m < d.M; ++m) {
+    if (!w->codebook[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: codebook[%d] is null", m));
+    if ((rc = upload_with_norms(h, w->codebook[m], d.K, d.D, &h->codebook[m], &h->cnorm[m]))) return bail(rc);
+    if (m == 0) continue;
+    if (d.A > 0) {
+      if (!w->sub_codebook[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: sub_codebook[%d] is null", m));
+      if ((rc = upload_with_norms(h, w->sub_codebook[m], d.K, d.D, &h->sub_codebook[m], &h->sub_cnorm[m]))) return bail(rc);
+    }
+    // packed stream, in the order mlp_kernel consumes it
+    const StreamDims& sd = h->sd;
+    std::vector<float> s;
+    s.reserve((size_t)(sd.total(d.L) + kRing) * 256);
+    if (sd.PROJ) {
+      if (!w->in_proj[m] || !w->out_proj[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: in/out_proj[%d] is null", m));
+      pack_kouter(s, w->in_proj[m], d.De, d.D, sd.T_IN);
+    }
+    if (!w->cat_w[m] || !w->cat_b[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: concat weights[%d] null", m));
+    pack_bias(s, w->cat_b[m], d.De, sd.T_BIAS);
+    pack_kouter(s, w->cat_w[m], d.De, d.De + d.D, sd.T_CAT);
+    for (int l = 0; l < d.L; ++l) {
+      const float* up = w->up[(size_t)m * d.L + l];
+      const float* dn = w->down[(size_t)m * d.L + l];
+      if (!up || !dn) return bail(fail(QINCO_ERR_INVALID, "qinco_create: FFN weights[%d][%d] null", m, l));
+      pack_obouter(s, up, d.Dh, d.De, sd.T_UP);
+      pack_obouter(s, dn, d.De, d.Dh, sd.T_DOWN);
+    }
+    if (sd.PROJ) pack_obouter(s, w->out_proj[m], d.D, d.De, sd.T_OUT);
+    if ((long)(s.size() / 256) != sd.total(d.L)) return bail(fail(QINCO_ERR_INVALID, "internal: stream size mismatch"));
+    s.resize(s.size() + (size_t)kRing * 256, 0.f);  // the ring prefetches P fragments past the end
+    float* ds = nullptr;
+    if ((rc = upload(h, &ds, s.data(), s.size()))) return bail(rc);
+    h->wstream[m] = reinterpret_cast<f32x4*>(ds);
+  }
+  if ((rc = ensure_scratch(h))) return bail(rc);
+  *out = h;
+  return QINCO_OK;
+}
+
+extern "C" int qinco_destroy(qinco_handle h) {
+  if (!h) return QINCO_OK;
+  (void)hipDeviceSynchronize();
+  for (void* p : h->owned)
+    if (p) (void)hipFree(p);
+  if (h->stage_x) (void)hipFree(h->stage_x);
+  if (h->stage_codes) (void)hipFree(h->stage_codes);
+  if (h->stage_out) (void)hipFree(h->stage_out);
+  for (auto& e : h->ev_pool) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  delete h;
+  return QINCO_OK;
+}
+
+extern "C" int qinco_set_beam(qinco_handle h, int32_t A, int32_t B) {
+  if (!h) return fail(QINCO_ERR_INVALID, "qinco_set_beam: null handle");
+  if (B < 1) return fail(QINCO_ERR_INVALID, "qinco_set_beam: B must be >= 1");
+  if (A < 0 || A > h->d.K) return fail(QINCO_ERR_INVALID, "qinco_set_beam: need 0 <= A <= K");
+  if (A > 0 && h->d.A == 0)
+    return fail(QINCO_ERR_INVALID,
+                "Can't evaluate a model trained with A=0 (no candidates pre-selection) using a non-zero A value.");
+  h->A = A;
+  h->B = B;
+  return ensure_scratch(h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------
+static unsigned ew_grid(long total) {
+  long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+static int launch_mlp(qinco_handle_s* h, const MlpArgs& a, hipStream_t st) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->prof) {
+    if (h->ev_used == h->ev_pool.size()) {
+      hipEvent_t a0, a1;
+      HIP_TRY(hipEventCreate(&a0));
+      HIP_TRY(hipEventCreate(&a1));
+      h->ev_pool.emplace_back(a0, a1);
+    }
+    e0 = h->ev_pool[h->ev_used].first;
+    e1 = h->ev_pool[h->ev_used].second;
+    h->ev_used++;
+    HIP_TRY(hipEventRecord(e0, st));
+  }
+  HIP_TRY(h->launch(&a, st));
+  if (h->prof) {
+    HIP_TRY(hipEventRecord(e1, st));
+    h->prof_flops += (double)a.R * mlp_flops_per_row(h->d);
+  }
+  return 0;
+}
+
+static int launch_dist_topk(qinco_handle_s* h, const float* x, const float* xhat, int F, const float* cb,
+                            const float* cn, long G, int T, int* ids, hipStream_t st) {
+  const qinco_desc& d = h->d;
+  size_t lds = ((size_t)DT_TG * d.D + 256 * DT_CP + (size_t)DT_TG * d.K + DT_TG) * sizeof(float);
+  unsigned grid = (unsigned)((G + DT_TG - 1) / DT_TG);
+  hipLaunchKernelGGL(dist_topk_kernel, dim3(grid), dim3(256), lds, st, x, xhat, F, cb, cn, d.K, d.D, G, T, ids);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t stride, int64_t n, void* codes_out,
+                        int code_dtype, float* xhat_out, int flags, hipStream_t st) {
+  const qinco_desc& d = h->d;
+  const int A = h->A, B = h->B, K = d.K, D = d.D, M = d.M;
+  hipLaunchKernelGGL(normalize_kernel, dim3(ew_grid(n * D)), dim3(256), 0, st, x, x_dtype, (long)stride,
+                     (flags & QINCO_FLAG_NORMALISED) ? (const float*)nullptr : h->mean, h->std_, h->xn, (long)n, D);
+  HIP_TRY(hipGetLastError());
+  // step 0: plain codebook, beam_0 = min(B, K0)  (qinco_inference.py:237-246); a single-step model ends at F = 1
+  int F = (M == 1) ? 1 : (B < K ? B : K);
+  int rc;
+  if ((rc = launch_dist_topk(h, h->xn, nullptr, 1, h->codebook[0], h->cnorm[0], n, F, h->top_ids, st))) return rc;
+  int cur = 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(n * F * (D / 4))), dim3(256), 0, st, h->codebook[0], h->top_ids,
+                     (long)n * F, D, h->xhat[cur], h->hist[cur], M);
+  HIP_TRY(hipGetLastError());
+  for (int m = 1; m < M; ++m) {
+    const int Fout_cfg = (m < M - 1) ? B : 1;  // qinco_inference.py:152
+    const int Ae = A > 0 ? A : K;
+    const long G = (long)n * F;
+    const int* cand_ids = nullptr;
+    if (A > 0) {
+      if ((rc = launch_dist_topk(h, h->xn, h->xhat[cur], F, h->sub_codebook[m], h->sub_cnorm[m], G, A, h->top_ids, st)))
+        return rc;
+      cand_ids = h->top_ids;
+    }
+    MlpArgs a{};
+    a.wstream = h->wstream[m];
+    a.L = d.L;
+    a.codebook = h->codebook[m];
+    a.cand_ids = cand_ids;
+    a.A = Ae;
+    a.F = F;
+    a.xhat = h->xhat[cur];
+    a.x = h->xn;
+    a.R = G * Ae;
+    a.cand_out = h->cand;
+    a.dist_out = h->dist;
+    a.add_c = d.qinco1_mode ? 0 : 1;
+    if ((rc = launch_mlp(h, a, st))) return rc;
+    const int C = F * Ae;
+    const int T = Fout_cfg < C ? Fout_cfg : C;
+    size_t lds = (size_t)4 * C * sizeof(float);
+    hipLaunchKernelGGL(beam_select_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, st, h->dist, h->cand, cand_ids,
+                       (long)n, F, Ae, D, T, m, M, h->hist[cur], h->hist[cur ^ 1], h->xhat[cur ^ 1]);
+    HIP_TRY(hipGetLastError());
+    cur ^= 1;
+    F = T;
+  }
+  hipLaunchKernelGGL(emit_codes_kernel, dim3(ew_grid(n * M)), dim3(256), 0, st, h->hist[cur], (long)n, F, M, codes_out,
+                     code_dtype);
+  HIP_TRY(hipGetLastError());
+  if (xhat_out) {
+    // F == 1 here for M > 1; for M == 1 beam 0 of each vector
+    HIP_TRY(hipMemcpy2DAsync(xhat_out, (size_t)D * 4, h->xhat[cur], (size_t)F * D * 4, (size_t)D * 4, (size_t)n,
+                             hipMemcpyDeviceToDevice, st));
+  }
+  return 0;
+}
+
+static size_t code_size(int dt) { return dt == QINCO_CODE_I64 ? 8 : dt == QINCO_CODE_I32 ? 4 : 1; }
+
+static int check_common(qinco_handle h, const void* a, const void* b, int64_t n, int code_dtype, const char* who) {
+  if (!h) return fail(QINCO_ERR_INVALID, "%s: null handle", who);
+  if (n < 0) return fail(QINCO_ERR_INVALID, "%s: n < 0", who);
+  if (n > 0 && (!a || !b)) return fail(QINCO_ERR_INVALID, "%s: null buffer", who);
+  if (code_dtype < 0 || code_dtype > 2) return fail(QINCO_ERR_INVALID, "%s: bad code dtype %d", who, code_dtype);
+  if (code_dtype == QINCO_CODE_U8 && h->d.K > 256) return fail(QINCO_ERR_INVALID, "%s: uint8 codes need K <= 256", who);
+  return 0;
+}
+
+extern "C" int qinco_encode(qinco_handle h, const void* x, int x_dtype, int64_t stride, int64_t n, void* codes_out,
+                            int code_dtype, float* xhat_out, int flags, void* stream) {
+  int rc = check_common(h, x, codes_out, n, code_dtype, "qinco_encode");
+  if (rc) return rc;
+  if (x_dtype != QINCO_X_F32 && x_dtype != QINCO_X_U8) return fail(QINCO_ERR_INVALID, "qinco_encode: bad x dtype %d", x_dtype);
+  const size_t esz = x_dtype == QINCO_X_F32 ? 4 : 1;
+  if (stride == 0) stride = (int64_t)(h->d.D * esz);
+  if (stride < (int64_t)(h->d.D * esz)) return fail(QINCO_ERR_INVALID, "qinco_encode: row stride smaller than a row");
+  if ((rc = ensure_scratch(h))) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int64_t i0 = 0; i0 < n; i0 += h->d.max_batch) {
+    int64_t nb = n - i0 < h->d.max_batch ? n - i0 : h->d.max_batch;
+    const char* xp = reinterpret_cast<const char*>(x) + i0 * stride;
+    char* cp = reinterpret_cast<char*>(codes_out) + (size_t)i0 * h->d.M * code_size(code_dtype);
+    float* xo = xhat_out ? xhat_out + (size_t)i0 * h->d.D : nullptr;
+    if ((rc = encode_chunk(h, xp, x_dtype, stride, nb, cp, code_dtype, xo, flags, st))) return rc;
+  }
+  return QINCO_OK;
+}
+
+static int decode_chunk(qinco_handle_s* h, const void* codes, int code_dtype, int64_t n, float* out, int flags,
+                        hipStream_t st) {
+  const qinco_desc& d = h->d;
+  const int D = d.D, M = d.M;
+  hipLaunchKernelGGL(import_codes_kernel, dim3(ew_grid(n * M)), dim3(256), 0, st, codes, code_dtype, (long)n, M, h->kvals,
+                     h->codes_t, h->err_flag);
+  HIP_TRY(hipGetLastError());
+  int cur = 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(n * (D / 4))), dim3(256), 0, st, h->codebook[0], h->codes_t, (long)n, D,
+                     h->xhat[cur], (int*)nullptr, M);
+  HIP_TRY(hipGetLastError());
+  for (int m = 1; m < M; ++m) {
+    MlpArgs a{};
+    a.wstream = h->wstream[m];
+    a.L = d.L;
+    a.codebook = h->codebook[m];
+    a.cand_ids = h->codes_t + (size_t)m * n;
+    a.A = 1;
+    a.F = 1;
+    a.xhat = h->xhat[cur];
+    a.x = nullptr;
+    a.R = n;
+    a.cand_out = h->xhat[cur ^ 1];  // xhat += f_m(c, xhat)  (qinco_inference.py:72-74)
+    a.dist_out = nullptr;
+    a.add_c = d.qinco1_mode ? 0 : 1;
+    int rc = launch_mlp(h, a, st);
+    if (rc) return rc;
+    cur ^= 1;
+  }
+  hipLaunchKernelGGL(denormalize_kernel, dim3(ew_grid(n * D)), dim3(256), 0, st, h->xhat[cur],
+                     (flags & QINCO_FLAG_NORMALISED) ? (const float*)nullptr : h->mean, h->std_, out, (long)n, D);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int qinco_decode(qinco_handle h, const void* codes, int code_dtype, int64_t n, float* out, int flags,
+                            void* stream) {
+  int rc = check_common(h, codes, out, n, code_dtype, "qinco_decode");
+  if (rc) return rc;
+  if ((rc = ensure_scratch(h))) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int64_t i0 = 0; i0 < n; i0 += h->d.max_batch) {
+    int64_t nb = n - i0 < h->d.max_batch ? n - i0 : h->d.max_batch;
+    const char* cp = reinterpret_cast<const char*>(codes) + (size_t)i0 * h->d.M * code_size(code_dtype);
+    if ((rc = decode_chunk(h, cp, code_dtype, nb, out + (size_t)i0 * h->d.D, flags, st))) return rc;
+  }
+  return QINCO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-pointer forms
+// ---------------------------------------------------------------------------------------------
+static int ensure_stage(void** p, size_t* cap, size_t need) {
+  if (*cap >= need) return 0;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  HIP_TRY(hipMalloc(p, need ? need : 16));
+  *cap = need;
+  return 0;
+}
+
+extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int64_t stride, int64_t n, void* codes_out,
+                                 int code_dtype, float* xhat_out, int flags) {
+  int rc = check_common(h, x, codes_out, n, code_dtype, "qinco_encode_host");
+  if (rc) return rc;
+  if (x_dtype != QINCO_X_F32 && x_dtype != QINCO_X_U8) return fail(QINCO_ERR_INVALID, "qinco_encode_host: bad x dtype");
+  if (n == 0) return QINCO_OK;
+  const size_t esz = x_dtype == QINCO_X_F32 ? 4 : 1;
+  const size_t rowb = (size_t)h->d.D * esz;
+  if (stride == 0) stride = (int64_t)rowb;
+  if (stride < (int64_t)rowb) return fail(QINCO_ERR_INVALID, "qinco_encode_host: row stride smaller than a row");
+  const size_t cb = (size_t)n * h->d.M * code_size(code_dtype);
+  if ((rc = ensure_stage(&h->stage_x, &h->stage_x_bytes, (size_t)n * rowb))) return rc;
+  if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, cb))) return rc;
+  if (xhat_out && (rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, (size_t)n * h->d.D * 4))) return rc;
+  HIP_TRY(hipMemcpy2D(h->stage_x, rowb, x, (size_t)stride, rowb, (size_t)n, hipMemcpyHostToDevice));
+  if ((rc = qinco_encode(h, h->stage_x, x_dtype, 0, n, h->stage_codes, code_dtype, xhat_out ? h->stage_out : nullptr, flags,
+                         nullptr)))
+    return rc;
+  HIP_TRY(hipMemcpy(codes_out, h->stage_codes, cb, hipMemcpyDeviceToHost));
+  if (xhat_out) HIP_TRY(hipMemcpy(xhat_out, h->stage_out, (size_t)n * h->d.D * 4, hipMemcpyDeviceToHost));
+  return QINCO_OK;
+}
+
+static int check_decode_range(qinco_handle_s* h) {
+  int flag = 0;
+  HIP_TRY(hipMemcpy(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) {
+    HIP_TRY(hipMemset(h->err_flag, 0, sizeof(int)));
+    return fail(QINCO_ERR_RANGE, "qinco_decode: a code is outside [0, K)");
+  }
+  return 0;
+}
+
+extern "C" int qinco_decode_host(qinco_handle h, const void* codes, int code_dtype, int64_t n, float* out, int flags) {
+  int rc = check_common(h, codes, out, n, code_dtype, "qinco_decode_host");
+  if (rc) return rc;
+  if (n == 0) return QINCO_OK;
+  const size_t cb = (size_t)n * h->d.M * code_size(code_dtype);
+  const size_t ob = (size_t)n * h->d.D * 4;
+  if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, cb))) return rc;
+  if ((rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, ob))) return rc;
+  HIP_TRY(hipMemcpy(h->stage_codes, codes, cb, hipMemcpyHostToDevice));
+  if ((rc = qinco_decode(h, h->stage_codes, code_dtype, n, h->stage_out, flags, nullptr))) return rc;
+  HIP_TRY(hipMemcpy(out, h->stage_out, ob, hipMemcpyDeviceToHost));
+  return check_decode_range(h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling / accounting
+// ---------------------------------------------------------------------------------------------
+extern "C" int qinco_profile_enable(qinco_handle h, int enable) {
+  if (!h) return fail(QINCO_ERR_INVALID, "qinco_profile_enable: null handle");
+  h->prof = enable != 0;
+  return QINCO_OK;
+}
+
+extern "C" int qinco_profile_read(qinco_handle h, double* mlp_ms, int64_t* mlp_launches, double* mlp_flops) {
+  if (!h) return fail(QINCO_ERR_INVALID, "qinco_profile_read: null handle");
+  HIP_TRY(hipDeviceSynchronize());
+  double ms = 0.0;
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, h->ev_pool[i].first, h->ev_pool[i].second));
+    ms += t;
+  }
+  if (mlp_ms) *mlp_ms = ms;
+  if (mlp_launches) *mlp_launches = (int64_t)h->ev_used;
+  if (mlp_flops) *mlp_flops = h->prof_flops;
+  h->ev_used = 0;
+  h->prof_flops = 0.0;
+  return QINCO_OK;
+}
+
+extern "C" double qinco_flops_per_vector_encode(qinco_handle h) {
+  if (!h) return 0.0;
+  const qinco_desc& d = h->d;
+  const double Ae = h->A > 0 ? h->A : d.K;
+  const double rm = mlp_flops_per_row(d);
+  double total = 2.0 * d.D * d.K;  // step 0 table
+  int F = (d.M == 1) ? 1 : (h->B < d.K ? h->B : d.K);
+  for (int m = 1; m < d.M; ++m) {
+    total += F * Ae * rm;                              // MLP
+    if (h->A > 0) total += (double)F * d.K * 2.0 * d.D;  // pre-selection table
+    total += F * Ae * 2.0 * d.D;                        // candidate distances
+    int Fout = (m < d.M - 1) ? h->B : 1;
+    F = Fout < F * Ae ? Fout : (int)(F * Ae);
+  }
+  return total;
+}
+
+extern "C" double qinco_flops_per_vector_decode(qinco_handle h) {
+  if (!h) return 0.0;
+  return (double)(h->d.M - 1) * mlp_flops_per_row(h->d);
+}
+
+extern "C" const char* qinco_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* qinco_version(void) { return "qinco_hip 0.1 (gfx950)"; }

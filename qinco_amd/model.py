@@ -1,0 +1,100 @@
+"""Drop-in model object for the reference's encode / decode call sites.
+
+`QINCoHIP` exposes the surface that qinco_tasks / search_tasks use on a QINCo / QINCoInferenceWrapper
+(SURVEY.md 8b): model(x, step="encode") -> (M, N) int64, model(codes, step="decode") -> (N, D) float32,
+.encode(x_norm) -> (codes_MB, xhat_BD), .decode(codes_MB), .built / .build(), .load_state_dict(sd), .eval(),
+.to(device), .data_mean / .data_std, get_codebooks_refs().  All arithmetic runs in libqinco_hip (HIP, gfx950);
+there is no CPU implementation behind this class.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .checkpoint import load_checkpoint, state_dict_to_numpy
+from .config import QincoConfig
+from .engine import QincoEngine, _is_torch
+
+
+class QINCoHIP:
+    def __init__(self, cfg: QincoConfig, state_dict: Optional[dict] = None, max_batch: int = 8192,
+                 device: Optional[int] = None):
+        self.cfg = cfg
+        self.max_batch = max_batch
+        self.device = device
+        self.built = False
+        self.engine: Optional[QincoEngine] = None
+        self._sd: Optional[dict] = None
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    # ---- construction ---------------------------------------------------------------------------
+    @classmethod
+    def from_checkpoint(cls, path: str, A: Optional[int] = None, B: Optional[int] = None, **kw) -> "QINCoHIP":
+        cfg, sd = load_checkpoint(path, A, B)
+        return cls(cfg, sd, **kw)
+
+    def load_state_dict(self, state_dict: dict, **_):
+        """QINCoInferenceWrapper.load_state_dict: load, then rebuild (qinco_inference.py:285-288)."""
+        self._sd = state_dict_to_numpy(state_dict)
+        self.build()
+
+    def build(self):
+        if self._sd is None:
+            raise RuntimeError("build() needs weights: call load_state_dict first")
+        if not float(np.asarray(self._sd.get("data_std", 0.0)).reshape(-1)[0]) > 0:
+            raise AssertionError("data_std must be > 0")  # qinco_base.py:526
+        if self.engine is not None:
+            self.engine.close()
+        self.engine = QincoEngine(self.cfg, self._sd, max_batch=self.max_batch, device=self.device)
+        self.data_mean = self._sd["data_mean"]
+        self.data_std = self._sd["data_std"]
+        self.built = True
+
+    def eval(self):
+        return self
+
+    def to(self, device=None):
+        return self
+
+    def set_search(self, A: Optional[int] = None, B: Optional[int] = None):
+        self.cfg = self.cfg.with_search(A, B)
+        self.engine.set_beam(self.cfg.A, self.cfg.B)
+
+    def get_codebooks_refs(self):
+        """qinco_base.py:541-549: per step, [codebook] (+ [substep codebook])."""
+        refs = []
+        for m in range(self.cfg.M):
+            r = [self._sd[f"steps.{m}.codebook.weight"]]
+            k = f"steps.{m}.substep.codebook.weight"
+            if k in self._sd:
+                r.append(self._sd[k])
+            refs.append(r)
+        return refs
+
+    # ---- forward --------------------------------------------------------------------------------
+    def __call__(self, x_in, *args, step: str = "train", **kwargs):
+        """QINCoInferenceWrapper.forward (qinco_inference.py:272-283)."""
+        assert step in ["encode", "decode"]
+        if not self.built:
+            raise RuntimeError("model not built")
+        if step == "encode":
+            return self._t(self.engine.encode(x_in))
+        return self.engine.decode(self._t(x_in))
+
+    forward = __call__
+
+    @staticmethod
+    def _t(a):
+        """(n, M) <-> (M, n): the model speaks (M, N), the ABI and the files (N, M) (search_tasks.py:115)."""
+        return a.T if not _is_torch(a) else a.transpose(0, 1)
+
+    def encode(self, x_norm):
+        """QINCoInferenceWrapper.encode(x_target_BD) -> (codes_MB, xhat_BD), both in normalised space (:340-350)."""
+        codes, xhat = self.engine.encode(x_norm, return_xhat=True, normalised=True)
+        return self._t(codes), xhat
+
+    def decode(self, codes_MB):
+        """QINCoInferenceWrapper.decode(codes_MB) -> normalised reconstruction (:330-337)."""
+        return self.engine.decode(self._t(codes_MB), normalised=True)

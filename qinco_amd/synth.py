@@ -1,0 +1,61 @@
+"""Deterministic synthetic checkpoints and inputs in the reference's state-dict layout.
+
+No trained weights or datasets are available offline, so parity and throughput are
+measured on seeded synthetic models.  Everything is drawn from numpy RandomState so the GPU box regenerates
+bit-identical weights without torch RNG.  Parameter names: qinco/model/qinco_base.py:229-260, 432-445.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .config import QincoConfig
+
+F32 = np.float32
+
+
+def synth_state_dict(cfg: QincoConfig, seed: int = 1234, gain: float = 0.6,
+                     data_std: float = 2.0, xhat_gain: float = 0.15) -> dict:
+    rs = np.random.RandomState(seed)
+    D, De, Dh = cfg.D, cfg.De, cfg.dh
+    sd: dict = {}
+    sd["data_mean"] = (0.5 * rs.randn(D)).astype(F32)
+    sd["data_std"] = np.asarray(data_std, dtype=F32)
+
+    def lin(o, i):
+        return (rs.randn(o, i) * (gain / np.sqrt(i))).astype(F32)
+
+    for m in range(cfg.M):
+        p = f"steps.{m}."
+        cb = (rs.randn(cfg.K, D) * (0.6 ** m)).astype(F32)
+        sd[p + "codebook.weight"] = cb
+        sd[p + "xtarget_mean"] = np.zeros(D, F32)   # training buffers, unused at inference
+        sd[p + "xtarget_var"] = np.ones(D, F32)
+        if m == 0:
+            continue
+        if cfg.A > 0:
+            noise = rs.randn(cfg.K, D).astype(F32) * F32(0.1 * float(cb.std()))
+            sd[p + "substep.codebook.weight"] = (cb + noise).astype(F32)
+        wc = lin(De, De + D)
+        wc[:, De:] *= F32(xhat_gain)   # keep f(c, xhat) dominated by c, as in a trained residual quantiser
+        sd[p + "concat.mlp.weight"] = wc
+        sd[p + "concat.mlp.bias"] = (0.05 * rs.randn(De)).astype(F32)
+        for l in range(cfg.L):
+            sd[p + f"residual_blocks.{l}.up_proj.weight"] = lin(Dh, De)
+            sd[p + f"residual_blocks.{l}.down_proj.weight"] = lin(De, Dh)
+        if De != D:
+            sd[p + "in_proj.weight"] = lin(De, D)
+            sd[p + "out_proj.weight"] = lin(D, De)
+    return sd
+
+
+def synth_vectors(cfg: QincoConfig, sd: dict, n: int, seed: int = 42) -> np.ndarray:
+    """S0 inputs: x = mean + std * N(0, I) in fp32 (normalises to ~N(0, I))."""
+    rs = np.random.RandomState(seed)
+    z = rs.randn(n, cfg.D).astype(F32)
+    return (z * F32(sd["data_std"]) + sd["data_mean"]).astype(F32)
+
+
+def synth_codes(cfg: QincoConfig, n: int, seed: int = 7) -> np.ndarray:
+    """Uniform random codes (M, n) int64 for decode tests / the structured S1 inputs."""
+    rs = np.random.RandomState(seed)
+    return rs.randint(0, cfg.K, size=(cfg.M, n)).astype(np.int64)

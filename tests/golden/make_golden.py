@@ -1,0 +1,162 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference (build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference (never present on the GPU box)
+
+For each case: a seeded synthetic checkpoint (qinco_amd.synth, numpy RandomState -> regenerated bit-identically
+by the tests) is loaded into the reference's QINCo model; inputs are run through BOTH reference
+implementations (QINCoInferenceWrapper = TorchScript inference path, and the base QINCo model) on the CPU fp32
+path, and the outputs are stored: codes (N, M), decoded vectors, the normalised reconstruction returned by
+encode, per-step pre-selection ids and the candidate-distance margin at each selection (to flag near-ties).
+Also writes tiny_ckpt.pt through the reference's own save_model to pin the checkpoint layout reader.
+
+Only data (inputs / expected outputs) is written; no reference source is copied.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+from types import SimpleNamespace as NS
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, "/root/reference")
+
+from qinco.model import QINCo, QINCoInferenceWrapper  # noqa: E402  (the reference)
+
+from qinco_amd.config import QincoConfig, preset  # noqa: E402
+from qinco_amd.synth import synth_codes, synth_state_dict, synth_vectors  # noqa: E402
+from oracle.qinco_oracle import OracleQINCo  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+class Acc:
+    device = torch.device("cpu")
+    is_main_process = True
+    num_processes = 1
+    process_index = 0
+
+    def print(self, *a, **k):
+        pass
+
+
+def ref_cfg(cfg: QincoConfig, batch: int = 64):
+    return NS(A=cfg.A, B=cfg.B, K=cfg.K, L=cfg.L, de=cfg.de, dh=cfg.dh, M=cfg.M, _D=cfg.D, _M_ivf=cfg.M,
+              _K_vals=[cfg.K] * cfg.M, _ivf_book=None, qinco1_mode=cfg.qinco1_mode, _qinco_jit=False,
+              _accelerator=Acc(), task="eval", enc_max_bs=65536, ivf_in_use=None, batch=batch,
+              codebook_noise_init=0.1, ivf_K=None, inference=True)
+
+
+def build_reference(cfg: QincoConfig, sd: dict):
+    rc = ref_cfg(cfg)
+    with torch.no_grad():
+        model = QINCo(rc)
+        missing = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+    model.eval()
+    wrapper = None
+    if not (cfg.A == 0 and cfg.B > 1):  # the inference wrapper is greedy-only for A = 0
+        wrapper = QINCoInferenceWrapper(rc, model)
+        wrapper.build()
+    return model, wrapper
+
+
+# name -> (config, seed, n_encode, structured?)
+CASES = {
+    "tiny_proj_beam": (QincoConfig(D=32, M=4, K=256, L=2, de=64, dh=96, A=8, B=4), 11, 256),
+    "tiny_proj_greedyA": (QincoConfig(D=32, M=4, K=256, L=2, de=64, dh=96, A=8, B=1), 12, 256),
+    "tiny_id_qinco1": (QincoConfig(D=32, M=4, K=256, L=2, de=None, dh=64, A=0, B=1, qinco1_mode=True), 13, 256),
+    "tiny_id_A0_beam": (QincoConfig(D=32, M=3, K=256, L=1, de=None, dh=64, A=0, B=3, qinco1_mode=False), 14, 64),
+    "C1_qinco1_8x8": (preset("qinco1", D=128, M=8), 1235, 128),
+    "C2_qinco2L_8x8_b8": (preset("qinco2-L", D=128, M=8, B=8), 1236, 64),
+    "C2_qinco2L_8x8_b1": (preset("qinco2-L", D=128, M=8, B=1), 1236, 64),
+    "C4_qinco2L_d768_b8": (preset("qinco2-L", D=768, M=4, B=8), 1238, 32),
+}
+
+
+def run_case(name: str, cfg: QincoConfig, seed: int, n: int) -> dict:
+    sd = synth_state_dict(cfg, seed)
+    model, wrapper = build_reference(cfg, sd)
+    oracle = OracleQINCo(sd, M=cfg.M, K=cfg.K, L=cfg.L, A=cfg.A, B=cfg.B, qinco1_mode=cfg.qinco1_mode)
+
+    x0 = synth_vectors(cfg, sd, n, seed=seed + 1)
+    # S1 "structured" half: x = decode(random codes) + small noise, so that beams really compete
+    rc = synth_codes(cfg, n // 2, seed=seed + 2)
+    with torch.no_grad():
+        xs = model(torch.from_numpy(rc), step="decode").numpy()
+    xs = (xs + 0.05 * float(sd["data_std"]) * np.random.RandomState(seed + 3).randn(*xs.shape)).astype(np.float32)
+    x = np.concatenate([x0[: n - n // 2], xs]).astype(np.float32)
+
+    out = {"x": x}
+    wrapper_ok = wrapper is not None
+    with torch.no_grad():
+        xt = torch.from_numpy(x)
+        codes_base = model(xt, step="encode").numpy()  # (M, N)
+        if wrapper_ok:
+            codes_w = wrapper(xt, step="encode").numpy()
+            _, xhat_norm = wrapper.encode((xt - wrapper.data_mean) / wrapper.data_std)
+            out["codes_wrapper"] = codes_w.T.copy()
+            out["xhat_norm_wrapper"] = xhat_norm.numpy()
+            dec = wrapper(torch.from_numpy(codes_w), step="decode").numpy()
+        else:
+            dec = model(torch.from_numpy(codes_base), step="decode").numpy()
+        out["codes_base"] = codes_base.T.copy()
+        out["decoded"] = dec
+        # decode of arbitrary codes (not produced by encode)
+        rc2 = synth_codes(cfg, 96, seed=seed + 5)
+        out["rand_codes"] = rc2.T.copy()
+        if wrapper_ok:
+            out["rand_decoded_wrapper"] = wrapper(torch.from_numpy(rc2), step="decode").numpy()
+        out["rand_decoded_base"] = model(torch.from_numpy(rc2), step="decode").numpy()
+
+    # oracle trace: pre-selection ids and selection margins (near-tie diagnostics)
+    trace: dict = {}
+    xn = (x - oracle.data_mean) / oracle.data_std
+    codes_o, xhat_o = oracle.encode(xn, trace)
+    codes_ref = out.get("codes_wrapper", out["codes_base"])
+    agree = float((codes_o.T == codes_ref).all(axis=1).mean())
+    margins = []
+    for m in range(1, cfg.M):
+        d = np.sort(trace[f"dists{m}"], axis=-1)
+        fo = min(cfg.B if m < cfg.M - 1 else 1, d.shape[1] - 1)
+        margins.append((d[:, fo] - d[:, fo - 1]) / np.maximum(np.abs(d[:, fo]), 1e-12))
+        if f"top{m}" in trace:
+            out[f"oracle_top{m}"] = trace[f"top{m}"].astype(np.int16)
+    out["select_rel_margin"] = np.stack(margins, axis=1).astype(np.float32)  # (N, M-1)
+    mse_ref = float(((x - dec) ** 2).sum(-1).mean())
+    out["mse"] = np.float64(mse_ref)
+    print(f"{name:24s} N={len(x):4d} wrapper==base: "
+          f"{bool((out['codes_base'] == codes_ref).all())}  oracle==ref rows: {agree:.4f}  "
+          f"min margin {out['select_rel_margin'].min():.2e}  mse {mse_ref:.4f}")
+    return out
+
+
+def write_tiny_checkpoint():
+    """A checkpoint written by the reference's own save_model (qinco/utils.py:100-137)."""
+    from qinco.utils import SharedCfgState, save_model
+    cfg, seed, _ = CASES["tiny_proj_beam"]
+    sd = synth_state_dict(cfg, seed)
+    model, _ = build_reference(cfg, sd)
+    path = HERE / "tiny_ckpt.pt"
+    c = SharedCfgState(dict(output=str(path), K=cfg.K, M=cfg.M, de=cfg.de, dh=cfg.dh, L=cfg.L, A=cfg.A, B=cfg.B,
+                            ivf_in_use=None, ivf_K=None, qinco1_mode=cfg.qinco1_mode))
+    c._cur_epoch = c._optimizer = c._scheduler = c._melog = None
+    c._D = cfg.D
+    save_model(c, Acc(), model)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for name, (cfg, seed, n) in CASES.items():
+        if only and name not in only:
+            continue
+        out = run_case(name, cfg, seed, n)
+        np.savez_compressed(HERE / f"{name}.npz", **out)
+    if not only:
+        write_tiny_checkpoint()

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Extra measurements next to bench.py (not part of the driver contract): encode AND decode throughput for each
+BASELINE.json workload (C1..C4), greedy and beam, with the fused-MLP kernel's roofline fraction.  One JSON line
+per (workload, mode).  Usage: python scripts/bench_extra.py [C1 C2 ...] [--batch N] [--steps K]"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+PEAK = 157.3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workloads", nargs="*", default=["C1", "C2", "C3", "C4"])
+    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--beams", type=int, nargs="*", default=None, help="override B (e.g. 1 8)")
+    args = ap.parse_args()
+    import torch
+    from qinco_amd import QincoEngine, synth_codes, synth_state_dict, synth_vectors
+    from qinco_amd.config import BASELINE_CONFIGS
+    dev = torch.device("cuda", 0)
+    for wl in args.workloads:
+        cfg0 = BASELINE_CONFIGS[wl]
+        sd = synth_state_dict(cfg0, 1236)
+        beams = args.beams or [cfg0.B]
+        eng = QincoEngine(cfg0, sd, max_batch=args.batch)
+        x = torch.from_numpy(synth_vectors(cfg0, sd, args.batch, seed=42)).to(dev)
+        for B in beams:
+            if cfg0.A == 0 and B > 1:
+                continue
+            eng.set_beam(B=B)
+            for mode in ("encode", "decode"):
+                if mode == "decode" and B != beams[0]:
+                    continue
+                nvec = args.batch if mode == "encode" else args.batch * 16
+                codes = torch.from_numpy(synth_codes(cfg0, nvec, seed=9).T.copy()).to(dev)
+                fn = (lambda: eng.encode(x, code_dtype=np.uint8)) if mode == "encode" else (lambda: eng.decode(codes))
+                fn()
+                torch.cuda.synchronize()
+                eng.profile_enable(True)
+                eng.profile_read()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    fn()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                pr = eng.profile_read()
+                eng.profile_enable(False)
+                tf = pr["mlp_flops"] / (pr["mlp_ms"] * 1e-3) / 1e12 if pr["mlp_ms"] else 0.0
+                print(json.dumps({"workload": wl, "mode": mode, "A": eng.A, "B": B, "vectors_per_step": nvec,
+                                  "vectors_per_s": args.steps * nvec / dt, "us_per_vector": dt / (args.steps * nvec) * 1e6,
+                                  "gflop_per_vector": eng.flops_per_vector(mode) / 1e9,
+                                  "mlp_tflops": tf, "mlp_frac_of_fp32_mfma_peak": tf / PEAK,
+                                  "mlp_share_of_time": pr["mlp_ms"] * 1e-3 / dt}), flush=True)
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""The C-ABI library: loads, exports every symbol include/qinco_hip.h declares, struct layouts agree with the
+ctypes mirror.  No compute calls here (no GPU in this tier)."""
+import ctypes as C
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from qinco_amd import _lib, build
+    build.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    txt = (ROOT / "include" / "qinco_hip.h").read_text()
+    return sorted(set(re.findall(r"QINCO_API[^;]*?\b(qinco_\w+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(lib):
+    from qinco_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 14 and set(syms) == set(_lib.API_SYMBOLS)
+    for s in syms:
+        assert getattr(lib, s) is not None
+    out = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (\w+)", out))
+    assert set(syms) <= exported
+    assert all(e.startswith("qinco_") for e in exported), exported   # nothing else leaks out of the .so
+
+
+def test_library_contains_gfx950_code_objects():
+    from qinco_amd import _lib
+    data = _lib.LIB_PATH.read_bytes()
+    assert b"gfx950" in data and b"mlp_kernel" in data
+    for other in (b"gfx942", b"gfx90a", b"sm_90"):
+        assert other not in data
+
+
+def test_struct_layouts_match_header():
+    from qinco_amd import _lib
+    src = r'''
+    #include "qinco_hip.h"
+    #include <stddef.h>
+    #include <stdio.h>
+    int main(void) {
+      printf("%zu %zu %zu %zu %zu %zu\n", sizeof(qinco_desc), offsetof(qinco_desc, max_batch), offsetof(qinco_desc, qinco1_mode),
+             sizeof(qinco_weights), offsetof(qinco_weights, codebook), offsetof(qinco_weights, down));
+      return 0; }'''
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", str(ROOT / "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        vals = [int(v) for v in subprocess.check_output([os.path.join(d, "t")]).split()]
+    D, W = _lib.QincoDesc, _lib.QincoWeights
+    assert vals == [C.sizeof(D), D.max_batch.offset, D.qinco1_mode.offset, C.sizeof(W), W.codebook.offset, W.down.offset]
+
+
+def test_shape_table(lib):
+    assert lib.qinco_shape_supported(128, 384, 384) == 1      # C2 / C3
+    assert lib.qinco_shape_supported(128, 128, 256) == 1      # C1
+    assert lib.qinco_shape_supported(768, 384, 384) == 1      # C4
+    assert lib.qinco_shape_supported(100, 384, 384) == 0
+    assert lib.qinco_version().startswith(b"qinco_hip")
+
+
+def test_fails_loudly_without_gpu():
+    """No CPU fallback: on a box without a GPU creating an engine must raise, not silently compute elsewhere."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from qinco_amd import QincoConfig, QincoEngine, synth_state_dict
+    cfg = QincoConfig(D=32, M=2, K=256, L=1, de=None, dh=64)
+    with pytest.raises(RuntimeError):
+        QincoEngine(cfg, synth_state_dict(cfg, 1))
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    from qinco_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("QINCO_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.QincoLibraryError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under qinco_amd/ may import or reference it."""
+    for p in (ROOT / "qinco_amd").rglob("*.py"):
+        txt = p.read_text()
+        assert "oracle" not in txt.replace("oracle-", ""), p

@@ -1,0 +1,128 @@
+"""Host logic around the hot path: sharding, part files, readers, and the world_size-2 gather on gloo (CPU).
+The model object here is an oracle-backed stand-in (tests only); the product path uses QINCoHIP."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_cases, make_oracle
+
+
+def test_shard_bounds_match_reference_formula():
+    from qinco_amd.encode_db import shard_bounds
+    for N in (0, 1, 7, 8, 1000, 1_000_003, 10**9):
+        for P in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(N, P, r) for r in range(P)]
+            assert spans[0][0] == 0 and spans[-1][1] == N
+            for r in range(P):
+                assert spans[r] == ((N // P) * r, (N // P) * (r + 1) if r < P - 1 else N)   # search_tasks.py:103-104
+                if r:
+                    assert spans[r][0] == spans[r - 1][1]
+
+
+def test_vecs_readers(tmp_path):
+    from qinco_amd.encode_db import get_data_memmap
+    rs = np.random.RandomState(0)
+    d, n = 12, 37
+    xb = rs.randint(0, 256, (n, d)).astype(np.uint8)
+    raw = np.zeros((n, d + 4), np.uint8)
+    raw[:, :4] = np.frombuffer(np.int32(d).tobytes(), np.uint8)
+    raw[:, 4:] = xb
+    raw.tofile(tmp_path / "a.bvecs")
+    got = get_data_memmap(str(tmp_path / "a.bvecs"))
+    assert got.shape == (n, d) and got.dtype == np.uint8 and got.strides == (d + 4, 1) and np.array_equal(got, xb)
+    xf = rs.randn(n, d).astype(np.float32)
+    rawf = np.zeros((n, d + 1), np.float32)
+    rawf[:, 0] = np.frombuffer(np.int32(d).tobytes(), np.float32)[0]
+    rawf[:, 1:] = xf
+    rawf.tofile(tmp_path / "a.fvecs")
+    assert np.array_equal(get_data_memmap(str(tmp_path / "a.fvecs")), xf)
+    xi = rs.randint(0, 1000, (n, d)).astype(np.int32)
+    np.concatenate([np.full((n, 1), d, np.int32), xi], axis=1).tofile(tmp_path / "a.ivecs")
+    assert np.array_equal(get_data_memmap(str(tmp_path / "a.ivecs")), xi)
+    np.save(tmp_path / "a.npy", xf)
+    assert np.array_equal(get_data_memmap(str(tmp_path / "a.npy")), xf)
+    with pytest.raises(ValueError):
+        get_data_memmap(str(tmp_path / "a.bin"))
+
+
+class OracleModel:
+    """Stand-in with the reference model's call signature (tests only)."""
+
+    def __init__(self, name):
+        from qinco_amd import synth_state_dict
+        self.cfg, seed = golden_cases()[name]
+        self.sd = synth_state_dict(self.cfg, seed)
+        self.o = make_oracle(self.cfg, self.sd)
+
+    def __call__(self, x, step):
+        return self.o(np.asarray(x, np.float32), step=step)
+
+
+def test_encode_database_single_process_files(tmp_path):
+    from qinco_amd import synth_vectors
+    from qinco_amd.encode_db import EncodedDBIterator, encode_database
+    model = OracleModel("tiny_proj_greedyA")
+    cfg = model.cfg
+    db = synth_vectors(cfg, model.sd, 301, seed=4)
+    out = str(tmp_path / "enc" / "db.npz")
+    codes = encode_database(model, db, out, K=cfg.K, M=cfg.M, D=cfg.D, batch=64)
+    assert codes.shape == (301, cfg.M) and codes.dtype == np.int64
+    assert np.array_equal(codes, model(db, step="encode").T)              # batching does not change codes
+    hdr = np.load(out)
+    assert {k: int(hdr[k]) for k in hdr.files} == {"n_parts": 1, "K": cfg.K, "M": cfg.M, "D": cfg.D}
+    part = np.load(out[:-4] + ".part_0.npz")["codes"]
+    assert part.dtype == np.int64 and np.array_equal(part, codes)
+    it = EncodedDBIterator(out, K=cfg.K, M=cfg.M, D=cfg.D)
+    assert np.array_equal(it.load_all(), codes)
+    chunks = list(it.iter(batch_size=100))
+    assert [len(c) for c in chunks] == [100, 100, 100, 1] and it.batch_end_id == 301
+    with pytest.raises(AssertionError):
+        EncodedDBIterator(out, M=cfg.M + 1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir, n):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qinco_amd import synth_vectors
+    from qinco_amd.encode_db import encode_database
+    model = OracleModel("tiny_proj_greedyA")
+    cfg = model.cfg
+    db = synth_vectors(cfg, model.sd, n, seed=4)
+    full = encode_database(model, db, os.path.join(outdir, "db.npz"), K=cfg.K, M=cfg.M, D=cfg.D, batch=50,
+                           dist=dist, gather=True)
+    if rank == 0:
+        np.save(os.path.join(outdir, "gathered.npy"), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 203), (3, 100)])
+def test_sharded_encode_equals_single_process_gloo(tmp_path, world, n):
+    """N>1 path on CPU: codes from P ranks (part files AND the gathered matrix) equal the 1-process codes bitwise."""
+    import torch.multiprocessing as mp
+    from qinco_amd import synth_vectors
+    from qinco_amd.encode_db import EncodedDBIterator, shard_bounds
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n), nprocs=world, join=True)
+    model = OracleModel("tiny_proj_greedyA")
+    want = model(synth_vectors(model.cfg, model.sd, n, seed=4), step="encode").T
+    assert np.array_equal(np.load(tmp_path / "gathered.npy"), want)
+    it = EncodedDBIterator(str(tmp_path / "db.npz"))
+    assert it.n_parts == world and np.array_equal(it.load_all(), want)
+    for r in range(world):
+        s, e = shard_bounds(n, world, r)
+        assert len(np.load(tmp_path / f"db.part_{r}.npz")["codes"]) == e - s

@@ -23,10 +23,10 @@ FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
          "-fvisibility=hidden"]
 
 
-def shapes() -> list[tuple[int, int, int]]:
+def shapes() -> list[tuple[int, int, int, int, int]]:
     txt = (CSRC / "shapes.def").read_text()
     return [tuple(int(v) for v in m.groups())
-            for m in re.finditer(r"^QINCO_SHAPE\((\d+),\s*(\d+),\s*(\d+)\)", txt, re.M)]
+            for m in re.finditer(r"^QINCO_SHAPE\((\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", txt, re.M)]
 
 
 def hipcc() -> str:
@@ -56,11 +56,11 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     headers = sorted(CSRC.glob("*.hpp")) + [CSRC / "shapes.def", PKG.parent / "include" / "qinco_hip.h"]
     tasks: list[tuple[Path, list[str]]] = []
     objs: list[Path] = []
-    for (d, de, dh) in shapes():
-        o = OBJ / f"mlp_{d}_{de}_{dh}.o"
+    for (d, de, dh, p, var) in shapes():
+        o = OBJ / f"mlp_{d}_{de}_{dh}_{p}_{var}.o"
         objs.append(o)
         if force or not _newer(o, mlp_deps):
-            tasks.append((o, [cc, *FLAGS, f"-DQD={d}", f"-DQDE={de}", f"-DQDH={dh}", "-c",
+            tasks.append((o, [cc, *FLAGS, f"-DQD={d}", f"-DQDE={de}", f"-DQDH={dh}", f"-DQP={p}", f"-DQVAR={var}", "-c",
                               str(CSRC / "mlp_inst.hip"), "-o", str(o)]))
     o = OBJ / "qinco_hip.o"
     objs.append(o)
@@ -72,6 +72,9 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
         with cf.ThreadPoolExecutor(max_workers=jobs or min(len(tasks), os.cpu_count() or 4)) as ex:
             for f in [ex.submit(_run, cmd) for _, cmd in tasks]:
                 f.result()
+    for stale in OBJ.glob("*.o"):
+        if stale not in objs:
+            stale.unlink()
     if force or tasks or not _newer(LIB, objs):
         _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)])
         if verbose:

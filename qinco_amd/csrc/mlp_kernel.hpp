@@ -60,12 +60,30 @@ QINCO_INL f32x16 zero16() {
 
 #define QINCO_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-template <int D, int DE, int DH, int P>
+// relu without the NaN-canonicalising v_max x,x,x that fmaxf() costs (relu(NaN) -> 0 either way on this path)
+QINCO_INL float relu1(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+QINCO_INL void relu16(f32x16& v) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = relu1(v[i]);
+}
+
+// VAR bit 0 (LAZY): chain epilogues are taken off the MFMA critical path.
+//   * up-projection chains accumulate straight into y[ob]; the ReLU of block ib is applied later, inside the
+//     first down-projection chain, one block ahead of its first use (its input is long finished: no drain);
+//   * the residual add z[ob] += acc of chain ob is issued after the first input block of chain ob+1 (two
+//     alternating accumulators); only the last chain of a layer is added eagerly.
+//   Without LAZY every chain end drains the matrix pipe and runs ~64 dependent VALU ops before the next MFMA.
+template <int D, int DE, int DH, int P, int VAR>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   constexpr StreamDims SL = stream_dims(D, DE, DH, P);
   constexpr int NDB = SL.NDB, NEB = SL.NEB, NHB = SL.NHB;
   constexpr bool PROJ = SL.PROJ;
   constexpr int NYB = NHB > NEB ? NHB : NEB;
+  constexpr bool LAZY = (VAR & 1) != 0;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -91,25 +109,32 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     ring[T % P] = wp[(T + P) * 64];
     return w;
   };
+  auto skip_pad = [&]<int FROM, int TO>() QINCO_LAMBDA {
+    static_for<TO - FROM>([&]<int i>() QINCO_LAMBDA { (void)take.template operator()<FROM + i>(); });
+  };
+  // 4 MFMAs of one fragment: acc += W[ob, 8 features of block ib] . b
+  auto mfma4 = [&]<int q>(f32x16& acc, const f32x4& w, const f32x16& b) QINCO_LAMBDA {
+    static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA(w[e], b[4 * q + e], acc); });
+  };
 
   f32x16 z[NEB];
   f32x16 y[NYB];
 
-  // ---- A: z = in_proj(c)  (K-outer; c blocks streamed from the codebook) ---------------------
+  // ---- A: z = in_proj(c)  (K-outer; c blocks streamed from the codebook, next block prefetched) ---------
   if constexpr (PROJ) {
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = zero16(); });
+    f32x16 cb = load_block(cptr);
     static_for<NDB>([&]<int ib>() QINCO_LAMBDA {
-      f32x16 cb = load_block(cptr + ib * 32);
+      f32x16 cur = cb;
+      if constexpr (ib + 1 < NDB) cb = load_block(cptr + (ib + 1) * 32);
       static_for<4>([&]<int q>() QINCO_LAMBDA {
         static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
           f32x4 w = take.template operator()<(ib * 4 + q) * NEB + ob>();
-          static_for<4>([&]<int e>() QINCO_LAMBDA { z[ob] = QINCO_MFMA(w[e], cb[4 * q + e], z[ob]); });
+          mfma4.template operator()<q>(z[ob], w, cur);
         });
       });
     });
-    static_for<SL.T_IN - NEB * NDB * 4>([&]<int i>() QINCO_LAMBDA {
-      (void)take.template operator()<NEB * NDB * 4 + i>();
-    });
+    skip_pad.template operator()<NEB * NDB * 4, SL.T_IN>();
     wp += SL.T_IN * 64;
   } else {
     static_for<NEB>([&]<int ib>() QINCO_LAMBDA { z[ib] = load_block(cptr + ib * 32); });
@@ -122,62 +147,95 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
       static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob][4 * q + e] = w[e]; });
     });
   });
-  static_for<SL.T_BIAS - NEB * 4>([&]<int i>() QINCO_LAMBDA {
-    (void)take.template operator()<NEB * 4 + i>();
-  });
+  skip_pad.template operator()<NEB * 4, SL.T_BIAS>();
   wp += SL.T_BIAS * 64;
 
   // ---- C: y += W_cat . [z ; xhat]   then z = z + y   (QConcat.forward) -------------------------
-  static_for<NEB + NDB>([&]<int ib>() QINCO_LAMBDA {
-    f32x16 b;
-    if constexpr (ib < NEB) b = z[ib];
-    else b = load_block(xhptr + (ib - NEB) * 32);
-    static_for<4>([&]<int q>() QINCO_LAMBDA {
-      static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-        f32x4 w = take.template operator()<(ib * 4 + q) * NEB + ob>();
-        static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob] = QINCO_MFMA(w[e], b[4 * q + e], y[ob]); });
+  {
+    f32x16 xb = load_block(xhptr);
+    static_for<NEB + NDB>([&]<int ib>() QINCO_LAMBDA {
+      f32x16 b;
+      if constexpr (ib < NEB) {
+        b = z[ib];
+      } else {
+        b = xb;
+        if constexpr (ib + 1 < NEB + NDB) xb = load_block(xhptr + (ib + 1 - NEB) * 32);
+      }
+      static_for<4>([&]<int q>() QINCO_LAMBDA {
+        static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+          f32x4 w = take.template operator()<(ib * 4 + q) * NEB + ob>();
+          mfma4.template operator()<q>(y[ob], w, b);
+        });
       });
     });
-  });
-  static_for<SL.T_CAT - NEB*(NEB + NDB) * 4>([&]<int i>() QINCO_LAMBDA {
-    (void)take.template operator()<NEB*(NEB + NDB) * 4 + i>();
-  });
+  }
+  skip_pad.template operator()<NEB*(NEB + NDB) * 4, SL.T_CAT>();
   wp += SL.T_CAT * 64;
   static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = z[ob] + y[ob]; });
 
   // ---- D: L residual FFN blocks: z = z + W_down . relu(W_up . z)   (QBlockFFN.forward) ---------
+  if constexpr (!LAZY) {
 #pragma unroll 1
-  for (int l = 0; l < a.L; ++l) {
-    static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
-      f32x16 acc = zero16();
-      static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
-        static_for<4>([&]<int q>() QINCO_LAMBDA {
-          f32x4 w = take.template operator()<(ob * NEB + ib) * 4 + q>();
-          static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA(w[e], z[ib][4 * q + e], acc); });
+    for (int l = 0; l < a.L; ++l) {
+      static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
+        f32x16 acc = zero16();
+        static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
+          static_for<4>([&]<int q>() QINCO_LAMBDA {
+            f32x4 w = take.template operator()<(ob * NEB + ib) * 4 + q>();
+            mfma4.template operator()<q>(acc, w, z[ib]);
+          });
+        });
+        relu16(acc);
+        y[ob] = acc;
+      });
+      skip_pad.template operator()<NHB * NEB * 4, SL.T_UP>();
+      wp += SL.T_UP * 64;
+      static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+        f32x16 acc = zero16();
+        static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
+          static_for<4>([&]<int q>() QINCO_LAMBDA {
+            f32x4 w = take.template operator()<(ob * NHB + ib) * 4 + q>();
+            mfma4.template operator()<q>(acc, w, y[ib]);
+          });
+        });
+        z[ob] = z[ob] + acc;
+      });
+      skip_pad.template operator()<NEB * NHB * 4, SL.T_DOWN>();
+      wp += SL.T_DOWN * 64;
+    }
+  } else {
+#pragma unroll 1
+    for (int l = 0; l < a.L; ++l) {
+      // up-projection: chains accumulate in place in y[ob]; no epilogue here
+      static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
+        y[ob] = zero16();
+        static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
+          static_for<4>([&]<int q>() QINCO_LAMBDA {
+            f32x4 w = take.template operator()<(ob * NEB + ib) * 4 + q>();
+            mfma4.template operator()<q>(y[ob], w, z[ib]);
+          });
         });
       });
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], 0.f);
-      y[ob] = acc;
-    });
-    static_for<SL.T_UP - NHB * NEB * 4>([&]<int i>() QINCO_LAMBDA {
-      (void)take.template operator()<NHB * NEB * 4 + i>();
-    });
-    wp += SL.T_UP * 64;
-    static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-      f32x16 acc = zero16();
-      static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
-        static_for<4>([&]<int q>() QINCO_LAMBDA {
-          f32x4 w = take.template operator()<(ob * NHB + ib) * 4 + q>();
-          static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA(w[e], y[ib][4 * q + e], acc); });
+      skip_pad.template operator()<NHB * NEB * 4, SL.T_UP>();
+      wp += SL.T_UP * 64;
+      // down-projection: lazy ReLU one block ahead, residual adds one chain behind
+      f32x16 acc[2];
+      relu16(y[0]);
+      static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+        acc[ob & 1] = zero16();
+        static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
+          static_for<4>([&]<int q>() QINCO_LAMBDA {
+            f32x4 w = take.template operator()<(ob * NHB + ib) * 4 + q>();
+            mfma4.template operator()<q>(acc[ob & 1], w, y[ib]);
+            if constexpr (q == 0 && ob == 0 && ib + 1 < NHB) relu16(y[ib + 1]);
+            if constexpr (q == 0 && ib == 0 && ob > 0) z[ob - 1] = z[ob - 1] + acc[(ob - 1) & 1];
+          });
         });
       });
-      z[ob] = z[ob] + acc;
-    });
-    static_for<SL.T_DOWN - NEB * NHB * 4>([&]<int i>() QINCO_LAMBDA {
-      (void)take.template operator()<NEB * NHB * 4 + i>();
-    });
-    wp += SL.T_DOWN * 64;
+      z[NEB - 1] = z[NEB - 1] + acc[(NEB - 1) & 1];  // the only chain end per layer that drains the pipe
+      skip_pad.template operator()<NEB * NHB * 4, SL.T_DOWN>();
+      wp += SL.T_DOWN * 64;
+    }
   }
 
   // ---- E: out_proj + epilogue: cand = (out + coeff*c) + xhat ; dist = |x|^2 + |cand|^2 - 2 x.cand
@@ -186,20 +244,25 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   float* outp = a.cand_out + row * D + half * 4;
   float s2 = 0.f, sx = 0.f, xn = 0.f;
   static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
+    // operands of this block's epilogue are fetched before its GEMM chain so their latency hides under it
+    f32x16 cblk, xhb, xb;
+    if (a.add_c) cblk = load_block(cptr + ob * 32);
+    xhb = load_block(xhptr + ob * 32);
+    if (xptr) xb = load_block(xptr + ob * 32);
     f32x16 o;
     if constexpr (PROJ) {
       o = zero16();
       static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
         static_for<4>([&]<int q>() QINCO_LAMBDA {
           f32x4 w = take.template operator()<(ob * NEB + ib) * 4 + q>();
-          static_for<4>([&]<int e>() QINCO_LAMBDA { o = QINCO_MFMA(w[e], z[ib][4 * q + e], o); });
+          mfma4.template operator()<q>(o, w, z[ib]);
         });
       });
     } else {
       o = z[ob];
     }
-    if (a.add_c) o = o + load_block(cptr + ob * 32);
-    o = o + load_block(xhptr + ob * 32);
+    if (a.add_c) o = o + cblk;
+    o = o + xhb;
     if (valid) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -208,7 +271,6 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
       }
     }
     if (xptr) {
-      f32x16 xb = load_block(xptr + ob * 32);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         s2 = fmaf(o[i], o[i], s2);

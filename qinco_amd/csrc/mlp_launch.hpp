@@ -1,10 +1,14 @@
-// Dispatch table for the per-shape fused-MLP kernel instances (see shapes.def).
+// Dispatch table for the fused-MLP kernel instances (see shapes.def).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace qinco {
 struct MlpArgs;
-constexpr int kRing = 8;  // weight prefetch ring depth (fragments of 1 KiB per wave)
 typedef hipError_t (*mlp_launch_fn)(const MlpArgs*, hipStream_t);
-mlp_launch_fn find_mlp_launcher(int D, int De, int Dh);
+struct MlpInstance {
+  int D, De, Dh, P, var;
+  mlp_launch_fn fn;
+};
+// want_P / want_var < 0: the production (first listed) instance of the shape.
+const MlpInstance* find_mlp_instance(int D, int De, int Dh, int want_P, int want_var);
 }  // namespace qinco

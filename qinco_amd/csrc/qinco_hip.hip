@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,18 +21,26 @@ using namespace qinco;
 // ---------------------------------------------------------------------------------------------
 // per-shape launchers (shapes.def)
 // ---------------------------------------------------------------------------------------------
-#define QINCO_SHAPE(D, DE, DH) \
-  extern "C" hipError_t qinco_mlp_launch_##D##_##DE##_##DH(const qinco::MlpArgs*, hipStream_t);
+#define QINCO_SHAPE(D, DE, DH, P, VAR) \
+  extern "C" hipError_t qinco_mlp_launch_##D##_##DE##_##DH##_##P##_##VAR(const qinco::MlpArgs*, hipStream_t);
 #include "shapes.def"
 #undef QINCO_SHAPE
 
 namespace qinco {
-mlp_launch_fn find_mlp_launcher(int D, int De, int Dh) {
-#define QINCO_SHAPE(d, de, dh) \
-  if (D == d && De == de && Dh == dh) return &qinco_mlp_launch_##d##_##de##_##dh;
+static const MlpInstance g_instances[] = {
+#define QINCO_SHAPE(d, de, dh, p, var) {d, de, dh, p, var, &qinco_mlp_launch_##d##_##de##_##dh##_##p##_##var},
 #include "shapes.def"
 #undef QINCO_SHAPE
-  return nullptr;
+};
+
+const MlpInstance* find_mlp_instance(int D, int De, int Dh, int want_P, int want_var) {
+  const MlpInstance* first = nullptr;
+  for (const MlpInstance& i : g_instances) {
+    if (i.D != D || i.De != De || i.Dh != Dh) continue;
+    if (!first) first = &i;
+    if (i.P == want_P && i.var == want_var) return &i;
+  }
+  return first;
 }
 }  // namespace qinco
 
@@ -64,7 +73,7 @@ struct qinco_handle_s {
   qinco_desc d{};
   int device = 0;
   int A = 0, B = 1;  // active search widths
-  mlp_launch_fn launch = nullptr;
+  const MlpInstance* inst = nullptr;
   StreamDims sd{};
 
   float* mean = nullptr;
@@ -84,6 +93,9 @@ struct qinco_handle_s {
   int* codes_t = nullptr;
   float* cand = nullptr;
   float* dist = nullptr;
+  // decode scratch: its own (larger) chunk, a decode row costs only 2 D floats + M ints
+  int64_t dec_cap = 0;
+  float* dxhat[2] = {nullptr, nullptr};
 
   // host-path staging
   void* stage_x = nullptr;
@@ -197,11 +209,11 @@ static int upload_with_norms(qinco_handle_s* h, const float* cb, int K, int D, f
 static int ensure_scratch(qinco_handle_s* h) {
   const qinco_desc& d = h->d;
   if (h->cap_n == d.max_batch && h->cap_A == h->A && h->cap_B == h->B) return 0;
-  void* old[] = {h->xn, h->xhat[0], h->xhat[1], h->hist[0], h->hist[1], h->top_ids, h->codes_t, h->cand, h->dist};
+  void* old[] = {h->xn, h->xhat[0], h->xhat[1], h->hist[0], h->hist[1], h->top_ids, h->cand, h->dist};
   HIP_TRY(hipDeviceSynchronize());
   for (void* p : old) dev_free(h, p);
   h->xn = h->xhat[0] = h->xhat[1] = h->cand = h->dist = nullptr;
-  h->hist[0] = h->hist[1] = h->top_ids = h->codes_t = nullptr;
+  h->hist[0] = h->hist[1] = h->top_ids = nullptr;
   h->cap_n = 0;
   const size_t n = (size_t)d.max_batch;
   const size_t Bm = (size_t)(h->B < d.K ? h->B : d.K);   // widest beam (beam_0 = min(B, K))
@@ -213,7 +225,6 @@ static int ensure_scratch(qinco_handle_s* h) {
     if ((rc = dev_alloc(h, &h->hist[i], n * Bm * d.M))) return rc;
   }
   if ((rc = dev_alloc(h, &h->top_ids, n * Bm * (Ae > Bm ? Ae : Bm)))) return rc;
-  if ((rc = dev_alloc(h, &h->codes_t, n * d.M))) return rc;
   if ((rc = dev_alloc(h, &h->cand, n * Bm * Ae * d.D))) return rc;
   if ((rc = dev_alloc(h, &h->dist, n * Bm * Ae))) return rc;
   h->cap_n = d.max_batch;
@@ -222,11 +233,34 @@ static int ensure_scratch(qinco_handle_s* h) {
   return 0;
 }
 
+// Decode processes up to kDecodeChunk rows per pass so that even small-max_batch handles fill the chip
+// (a pass needs rows/128 workgroups; 8192 rows would occupy only 64 of the 256 CUs).
+static constexpr int64_t kDecodeChunk = 262144;
+
+static int ensure_decode_scratch(qinco_handle_s* h, int64_t n) {
+  int64_t want = n < kDecodeChunk ? n : kDecodeChunk;
+  if (want < h->d.max_batch && n >= h->d.max_batch) want = h->d.max_batch;
+  if (want <= h->dec_cap) return 0;
+  HIP_TRY(hipDeviceSynchronize());
+  dev_free(h, h->dxhat[0]);
+  dev_free(h, h->dxhat[1]);
+  dev_free(h, h->codes_t);
+  h->dxhat[0] = h->dxhat[1] = nullptr;
+  h->codes_t = nullptr;
+  h->dec_cap = 0;
+  int rc;
+  for (int i = 0; i < 2; ++i)
+    if ((rc = dev_alloc(h, &h->dxhat[i], (size_t)want * h->d.D))) return rc;
+  if ((rc = dev_alloc(h, &h->codes_t, (size_t)want * h->d.M))) return rc;
+  h->dec_cap = want;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // create / destroy
 // ---------------------------------------------------------------------------------------------
 extern "C" int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh) {
-  return find_mlp_launcher(D, De, Dh) != nullptr;
+  return find_mlp_instance(D, De, Dh, -1, -1) != nullptr;
 }
 
 extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinco_handle* out) {
@@ -239,7 +273,9 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   if (d.K > 1024) return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: K=%d > 1024 not supported", d.K);
   if (d.A < 0 || d.A > d.K || d.B < 1) return fail(QINCO_ERR_INVALID, "qinco_create: need 0 <= A <= K and B >= 1");
   if (!(w->data_std > 0.f)) return fail(QINCO_ERR_INVALID, "qinco_create: data_std must be > 0 (qinco_base.py:526)");
-  mlp_launch_fn fn = find_mlp_launcher(d.D, d.De, d.Dh);
+  int want_P = -1, want_var = -1;  // A/B hook: QINCO_MLP_VARIANT="P,VAR" selects a non-production instance
+  if (const char* ev = getenv("QINCO_MLP_VARIANT")) sscanf(ev, "%d,%d", &want_P, &want_var);
+  const MlpInstance* fn = find_mlp_instance(d.D, d.De, d.Dh, want_P, want_var);
   if (!fn && d.M > 1)
     return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: no fused-MLP kernel instance for (D=%d, De=%d, Dh=%d); add it to csrc/shapes.def",
                 d.D, d.De, d.Dh);
@@ -255,8 +291,9 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   h->d = d;
   h->A = d.A;
   h->B = d.B;
-  h->launch = fn;
+  h->inst = fn;
   h->std_ = w->data_std;
+  const int kRing = fn ? fn->P : 8;
   h->sd = stream_dims(d.D, d.De, d.Dh, kRing);
   int rc = 0;
   auto bail = [&](int code) {
@@ -368,7 +405,7 @@ static int launch_mlp(qinco_handle_s* h, const MlpArgs& a, hipStream_t st) {
     h->ev_used++;
     HIP_TRY(hipEventRecord(e0, st));
   }
-  HIP_TRY(h->launch(&a, st));
+  HIP_TRY(h->inst->fn(&a, st));
   if (h->prof) {
     HIP_TRY(hipEventRecord(e1, st));
     h->prof_flops += (double)a.R * mlp_flops_per_row(h->d);
@@ -485,7 +522,7 @@ static int decode_chunk(qinco_handle_s* h, const void* codes, int code_dtype, in
   HIP_TRY(hipGetLastError());
   int cur = 0;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(n * (D / 4))), dim3(256), 0, st, h->codebook[0], h->codes_t, (long)n, D,
-                     h->xhat[cur], (int*)nullptr, M);
+                     h->dxhat[cur], (int*)nullptr, M);
   HIP_TRY(hipGetLastError());
   for (int m = 1; m < M; ++m) {
     MlpArgs a{};
@@ -495,17 +532,17 @@ static int decode_chunk(qinco_handle_s* h, const void* codes, int code_dtype, in
     a.cand_ids = h->codes_t + (size_t)m * n;
     a.A = 1;
     a.F = 1;
-    a.xhat = h->xhat[cur];
+    a.xhat = h->dxhat[cur];
     a.x = nullptr;
     a.R = n;
-    a.cand_out = h->xhat[cur ^ 1];  // xhat += f_m(c, xhat)  (qinco_inference.py:72-74)
+    a.cand_out = h->dxhat[cur ^ 1];  // xhat += f_m(c, xhat)  (qinco_inference.py:72-74)
     a.dist_out = nullptr;
     a.add_c = d.qinco1_mode ? 0 : 1;
     int rc = launch_mlp(h, a, st);
     if (rc) return rc;
     cur ^= 1;
   }
-  hipLaunchKernelGGL(denormalize_kernel, dim3(ew_grid(n * D)), dim3(256), 0, st, h->xhat[cur],
+  hipLaunchKernelGGL(denormalize_kernel, dim3(ew_grid(n * D)), dim3(256), 0, st, h->dxhat[cur],
                      (flags & QINCO_FLAG_NORMALISED) ? (const float*)nullptr : h->mean, h->std_, out, (long)n, D);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -515,10 +552,10 @@ extern "C" int qinco_decode(qinco_handle h, const void* codes, int code_dtype, i
                             void* stream) {
   int rc = check_common(h, codes, out, n, code_dtype, "qinco_decode");
   if (rc) return rc;
-  if ((rc = ensure_scratch(h))) return rc;
+  if ((rc = ensure_decode_scratch(h, n))) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  for (int64_t i0 = 0; i0 < n; i0 += h->d.max_batch) {
-    int64_t nb = n - i0 < h->d.max_batch ? n - i0 : h->d.max_batch;
+  for (int64_t i0 = 0; i0 < n; i0 += h->dec_cap) {
+    int64_t nb = n - i0 < h->dec_cap ? n - i0 : h->dec_cap;
     const char* cp = reinterpret_cast<const char*>(codes) + (size_t)i0 * h->d.M * code_size(code_dtype);
     if ((rc = decode_chunk(h, cp, code_dtype, nb, out + (size_t)i0 * h->d.D, flags, st))) return rc;
   }

@@ -60,12 +60,19 @@ QINCO_INL f32x16 zero16() {
 
 #define QINCO_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// relu without the NaN-canonicalising v_max x,x,x that fmaxf() costs (relu(NaN) -> 0 either way on this path)
+// relu as ONE integer VALU op (v_max_i32 0, bits): positive floats have non-negative bit patterns and keep their
+// order, negative floats (and -0.0) have the sign bit set and clamp to 0.  fmaxf() would cost two v_max_f32
+// here (the compiler canonicalises an MFMA result first), and inline asm would hide VALU->MFMA hazards from it.
 QINCO_INL float relu1(float v) {
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-  return r;
+  int b = __builtin_bit_cast(int, v);
+  b = b > 0 ? b : 0;
+  return __builtin_bit_cast(float, b);
 }
+// Register-class pins: empty asm statements that force a 16-register block into VGPRs / AGPRs at that point
+// (clang cannot reference lambda captures from an asm operand, hence the helpers).
+QINCO_INL void pin_v(f32x16& v) { asm volatile("" : "+v"(v)); }
+QINCO_INL void pin_a(f32x16& v) { asm volatile("" : "+a"(v)); }
+
 QINCO_INL void relu16(f32x16& v) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = relu1(v[i]);
@@ -84,6 +91,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   constexpr bool PROJ = SL.PROJ;
   constexpr int NYB = NHB > NEB ? NHB : NEB;
   constexpr bool LAZY = (VAR & 1) != 0;
+  constexpr bool LDSR = (VAR & 4) != 0;
+  constexpr bool PINNED = (VAR & 8) != 0;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -98,16 +107,50 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   const float* cptr = a.codebook + (long)cid * D + half * 4;
   const float* xhptr = a.xhat + g * D + half * 4;
 
-  // ---- weight stream with a P-deep register ring -------------------------------------------
+  // ---- weight stream ---------------------------------------------------------------------------------
+  // Two implementations of take<T>() = "fragment T of the current section" (sections start at multiples of P):
+  //  * register ring (VAR bit 2 clear): P fragments prefetched into VGPRs by plain global loads;
+  //  * LDS-DMA ring (VAR bit 2 set, LDSR): each wave owns P KiB of LDS (P = 32: 128 KiB per workgroup) that
+  //    global_load_lds_dwordx4 fills P-1 fragments (~8k cycles) ahead with no VGPR cost; a 2-deep register
+  //    pair is read from LDS one fragment ahead (ds_read_b128, lane-linear = conflict free).  Waves never touch
+  //    each other's ring, so there is no barrier; ordering is the issuing wave's own counted vmcnt / lgkmcnt.
+  //    The deep ring hides Infinity-Cache latency of the lock-stepped stream (9.7 % of wave time was parked in
+  //    s_waitcnt with the 8-deep register ring, profiles/r01_*).
   const f32x4* wp = a.wstream + lane;
-  f32x4 ring[P];
+  constexpr int NRING = LDSR ? 2 : P;
+  f32x4 ring[NRING];
+  __shared__ f32x4 lds_ring[LDSR ? 4 * P * 64 : 1];
+  [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  [[maybe_unused]] f32x4* myring = lds_ring + (LDSR ? wave_u * P * 64 : 0);
+  [[maybe_unused]] const unsigned lds_lane =
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)(myring) + (unsigned)lane * 16u;
+  // DMA of fragment T (relative to the current section origin wp) into its ring slot
+  auto dma = [&]<int T>() QINCO_LAMBDA {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + T * 64),
+                                     (__attribute__((address_space(3))) void*)(myring + (T % P) * 64), 16, 0, 0);
+  };
+  if constexpr (LDSR) {
+    static_assert(P % 2 == 0 && P >= 4 && P <= 40, "LDS ring depth");
+    static_for<P - 1>([&]<int i>() QINCO_LAMBDA { dma.template operator()<i>(); });
+    asm volatile("s_waitcnt vmcnt(%c2)\n\tds_read_b128 %0, %1 offset:0" : "=&v"(ring[0]) : "v"(lds_lane), "i"(P - 2));
+  } else {
 #pragma unroll
-  for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
-  // take<T>(): fragment T of the current section (sections start at multiples of P).
+    for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
+  }
   auto take = [&]<int T>() QINCO_LAMBDA -> f32x4 {
-    f32x4 w = ring[T % P];
-    ring[T % P] = wp[(T + P) * 64];
-    return w;
+    if constexpr (LDSR) {
+      // fragment T was ds_read one step ago: wait for it; fragment T+1's DMA is P-3 DMAs old: wait, read it;
+      // then refill the slot of fragment T-1 (its ds_read completed a step ago) with fragment T+P-1.
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(%c3)\n\tds_read_b128 %0, %2 offset:%c4"
+                   : "=&v"(ring[(T + 1) & 1]), "+v"(ring[T & 1])
+                   : "v"(lds_lane), "i"(P - 3), "i"(((T + 1) % P) * 1024));
+      dma.template operator()<T + P - 1>();
+      return ring[T & 1];
+    } else {
+      f32x4 w = ring[T % P];
+      ring[T % P] = wp[(T + P) * 64];
+      return w;
+    }
   };
   auto skip_pad = [&]<int FROM, int TO>() QINCO_LAMBDA {
     static_for<TO - FROM>([&]<int i>() QINCO_LAMBDA { (void)take.template operator()<FROM + i>(); });
@@ -174,7 +217,53 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = z[ob] + y[ob]; });
 
   // ---- D: L residual FFN blocks: z = z + W_down . relu(W_up . z)   (QBlockFFN.forward) ---------
-  if constexpr (!LAZY) {
+  if constexpr (PINNED) {
+    // Register-file plan (the compiler is told, not asked): z lives in VGPRs (B operand of the up-projection,
+    // VALU-updated by the residual add), y lives in AGPRs (B operand of the down-projection, never touched by
+    // VALU after it is written), chain accumulators t[2] are VGPR temporaries.  Epilogues run one chain late:
+    //   up:   y[ob-1] = relu(t_prev)  (16 v_max_i32 + 16 v_accvgpr_write) under chain ob's first MFMAs
+    //   down: z[ob-1] += t_prev       (16 v_add_f32, all-VGPR)            under chain ob's first MFMAs
+    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { pin_v(z[ob]); });
+#pragma unroll 1
+    for (int l = 0; l < a.L; ++l) {
+      f32x16 t[2];
+      static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
+        t[ob & 1] = zero16();
+        static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
+          static_for<4>([&]<int q>() QINCO_LAMBDA {
+            f32x4 w = take.template operator()<(ob * NEB + ib) * 4 + q>();
+            mfma4.template operator()<q>(t[ob & 1], w, z[ib]);
+            if constexpr (ib == 0 && ob > 0) {  // a quarter of the previous chain's epilogue per fragment
+              static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob - 1][4 * q + e] = relu1(t[(ob - 1) & 1][4 * q + e]); });
+              if constexpr (q == 3) pin_a(y[ob - 1]);
+            }
+          });
+        });
+      });
+      relu16(t[(NHB - 1) & 1]);
+      y[NHB - 1] = t[(NHB - 1) & 1];
+      pin_a(y[NHB - 1]);
+      skip_pad.template operator()<NHB * NEB * 4, SL.T_UP>();
+      wp += SL.T_UP * 64;
+      static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+        t[ob & 1] = zero16();
+        static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
+          static_for<4>([&]<int q>() QINCO_LAMBDA {
+            f32x4 w = take.template operator()<(ob * NHB + ib) * 4 + q>();
+            mfma4.template operator()<q>(t[ob & 1], w, y[ib]);
+            if constexpr (ib == 0 && ob > 0) {
+              static_for<4>([&]<int e>() QINCO_LAMBDA { z[ob - 1][4 * q + e] += t[(ob - 1) & 1][4 * q + e]; });
+              if constexpr (q == 3) pin_v(z[ob - 1]);
+            }
+          });
+        });
+      });
+      z[NEB - 1] = z[NEB - 1] + t[(NEB - 1) & 1];
+      pin_v(z[NEB - 1]);
+      skip_pad.template operator()<NEB * NHB * 4, SL.T_DOWN>();
+      wp += SL.T_DOWN * 64;
+    }
+  } else if constexpr (!LAZY) {
 #pragma unroll 1
     for (int l = 0; l < a.L; ++l) {
       static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
@@ -285,6 +374,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     xn += __shfl_xor(xn, 32);
     if (valid && half == 0) a.dist_out[row] = (xn + s2) - 2.f * sx;
   }
+  // no LDS-DMA may be in flight when the wave ends (its LDS could be handed to the next workgroup)
+  if constexpr (LDSR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace qinco

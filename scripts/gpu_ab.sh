@@ -1,18 +1,15 @@
 #!/bin/bash
-# A/B of fused-MLP kernel variants (QINCO_MLP_VARIANT="P,VAR") + stall-breakdown PMC pass.
+# A/B of fused-MLP kernel variants (QINCO_MLP_VARIANT="P,VAR") + parity of the production instances.
 set -x
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
-for v in "8,0" "8,1" "4,1" "8,0" "8,1"; do
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -15 $O/pytest_gpu.log
+for v in "8,0" "32,12" "8,8" "8,0" "32,12"; do
   echo "== C2 variant $v"; QINCO_MLP_VARIANT=$v timeout 600 python bench.py --steps 3 --warmup 1 --batch 8192 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['achieved'], d['roofline']['frac'])"
 done
-for v in "8,0" "8,1"; do
+for v in "8,0" "8,8" "32,12"; do
   echo "== C1 variant $v"; QINCO_MLP_VARIANT=$v timeout 600 python scripts/bench_extra.py C1 --steps 3 2>/dev/null | grep encode
 done
-timeout 600 python scripts/bench_extra.py C2 C4 --beams 8 --steps 2 2>/dev/null
+timeout 600 python scripts/bench_extra.py C3 C4 --beams 8 --steps 2 2>/dev/null
 cd /tmp
-rocprofv3 -L > $O/counters_list.txt 2>&1
 timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d $O/prof_pmc_stall -o pmc -- python $R/bench.py --steps 2 --warmup 1 --batch 8192 --no-cpu-baseline > $O/prof_pmc_stall.log 2>&1
-timeout 900 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-trace -d $O/prof_pmc_stall2 -o pmc -- python $R/bench.py --steps 2 --warmup 1 --batch 8192 --no-cpu-baseline > $O/prof_pmc_stall2.log 2>&1
-timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace -d $O/prof_pmc_cache -o pmc -- python $R/bench.py --steps 2 --warmup 1 --batch 8192 --no-cpu-baseline > $O/prof_pmc_cache.log 2>&1
 cd $R; ls $O

@@ -117,35 +117,47 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   //    The deep ring hides Infinity-Cache latency of the lock-stepped stream (9.7 % of wave time was parked in
   //    s_waitcnt with the 8-deep register ring, profiles/r01_*).
   const f32x4* wp = a.wstream + lane;
-  constexpr int NRING = LDSR ? 2 : P;
+  constexpr int NRING = LDSR ? 3 : P;
   f32x4 ring[NRING];
   __shared__ f32x4 lds_ring[LDSR ? 4 * P * 64 : 1];
   [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   [[maybe_unused]] f32x4* myring = lds_ring + (LDSR ? wave_u * P * 64 : 0);
-  [[maybe_unused]] const unsigned lds_lane =
-      (unsigned)(size_t)(__attribute__((address_space(3))) void*)(myring) + (unsigned)lane * 16u;
   // DMA of fragment T (relative to the current section origin wp) into its ring slot
   auto dma = [&]<int T>() QINCO_LAMBDA {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + T * 64),
                                      (__attribute__((address_space(3))) void*)(myring + (T % P) * 64), 16, 0, 0);
   };
+  // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields = "no wait"): the builtin keeps the wait visible to hipcc's
+  // own counter bookkeeping (an asm s_waitcnt made it fall back to lgkmcnt(0) everywhere); the empty asm fences
+  // pin the LDS reads / DMAs of the ring on their side of the wait.
+  auto wait_vm = [&]<int N>() QINCO_LAMBDA {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+  };
   if constexpr (LDSR) {
-    static_assert(P % 2 == 0 && P >= 4 && P <= 40, "LDS ring depth");
+    static_assert(P % 3 == 0 && P >= 6 && P <= 39, "LDS ring depth (3 register sets: P must be a multiple of 3)");
     static_for<P - 1>([&]<int i>() QINCO_LAMBDA { dma.template operator()<i>(); });
-    asm volatile("s_waitcnt vmcnt(%c2)\n\tds_read_b128 %0, %1 offset:0" : "=&v"(ring[0]) : "v"(lds_lane), "i"(P - 2));
+    wait_vm.template operator()<P - 2>();  // fragment 0 has landed
+    ring[0] = myring[lane];
+    wait_vm.template operator()<P - 3>();  // fragment 1
+    ring[1] = myring[64 + lane];
   } else {
 #pragma unroll
     for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
   }
   auto take = [&]<int T>() QINCO_LAMBDA -> f32x4 {
     if constexpr (LDSR) {
-      // fragment T was ds_read one step ago: wait for it; fragment T+1's DMA is P-3 DMAs old: wait, read it;
-      // then refill the slot of fragment T-1 (its ds_read completed a step ago) with fragment T+P-1.
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(%c3)\n\tds_read_b128 %0, %2 offset:%c4"
-                   : "=&v"(ring[(T + 1) & 1]), "+v"(ring[T & 1])
-                   : "v"(lds_lane), "i"(P - 3), "i"(((T + 1) % P) * 1024));
+      // ring[T&1] holds fragment T (LDS read issued one step ago; hipcc counts lgkmcnt for it and keeps its
+      // registers safe).  hipcc does NOT order a ds_read behind an in-flight LDS-DMA, so the DMA side is ours:
+      // fragment T+1's DMA is P-3 DMAs old -> counted vmcnt (a "memory" asm is also a fence that pins the LDS
+      // read and the DMA below).  Then refill the slot of fragment T-1 with fragment T+P-1.
+      // fragments T, T+1 are in ring[] (3 register sets, read two steps ahead so that the LDS latency hides
+      // wherever the scheduler puts the read); fragment T+2's DMA is P-4 DMAs old.
+      wait_vm.template operator()<P - 4>();
+      ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
       dma.template operator()<T + P - 1>();
-      return ring[T & 1];
+      return ring[T % 3];
     } else {
       f32x4 w = ring[T % P];
       ring[T % P] = wp[(T + P) * 64];

@@ -33,6 +33,17 @@ sys.path.insert(0, str(ROOT))
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
 
 
+def pmc_traffic_per_row():
+    """L2<->fabric bytes per MLP row from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE; profiles/r01_c2_traffic.json).  Counters cannot be read from inside this process, so the figure
+    of the separate PMC run of this same command is scaled to this run's rows per launch."""
+    try:
+        with open(ROOT / "profiles" / "r01_c2_traffic.json") as f:
+            return float(json.load(f)["bytes_per_row"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, sd, budget_s: float = 12.0, chunk: int = 32):
     """Oracle encode throughput on the host cores (rank 0, N=1 only): bounded sample of the same workload."""
     from oracle.qinco_oracle import OracleQINCo
@@ -129,6 +140,8 @@ def main():
         avg_ms = prof["mlp_ms"] / launches
         flops_per_launch = prof["mlp_flops"] / launches
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        bpr = pmc_traffic_per_row() if args.workload == "C2" else None
+        rows_per_launch = flops_per_launch / cfg.mlp_flops_per_row()
         out = {
             "metric": "encode vectors/sec (BigANN-shaped d=128 8x8, beam=%d)" % cfg.B,
             "value": value, "unit": "vectors/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -141,7 +154,9 @@ def main():
                        "gflop_per_vector": eng.flops_per_vector("encode") / 1e9},
             "roofline": {"bound": "mfma", "kernel": "qinco::mlp_kernel", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": None, "avg_launch_ms": avg_ms, "launches": prof["mlp_launches"],
+                         "traffic": (bpr * rows_per_launch if bpr else None),
+                         "traffic_unit": "bytes per launch (L2<->fabric, PMC pass in profiles/r01_c2_traffic.json)",
+                         "avg_launch_ms": avg_ms, "launches": prof["mlp_launches"],
                          "flops_per_launch": flops_per_launch,
                          "mlp_share_of_step_time": prof["mlp_ms"] * 1e-3 / dt if dt > 0 else None},
         }

@@ -53,7 +53,7 @@ def cpu_baseline(cfg, sd, budget_s: float = 12.0, chunk: int = 32):
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
     except Exception:
         threads = os.cpu_count() or 1
-    oracle = OracleQINCo(sd, M=cfg.M, K=cfg.K, L=cfg.L, A=cfg.A, B=cfg.B, qinco1_mode=cfg.qinco1_mode)
+    oracle = OracleQINCo.from_config(cfg, sd)
     x = synth_vectors(cfg, sd, 4096, seed=4242)
     oracle(x[:8], step="encode")  # warm-up
     done, t0 = 0, time.perf_counter()

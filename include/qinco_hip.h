@@ -55,12 +55,13 @@ typedef struct {
   int32_t De;           /* cfg.de, or D when de is None (QINCo1) */
   int32_t Dh;           /* cfg.dh */
   int32_t L;            /* residual blocks per step */
-  int32_t M;            /* number of steps (cfg._M_ivf; no IVF step in this version) */
-  int32_t K;            /* codebook size of every step */
+  int32_t M;            /* number of steps = columns of the code matrix (cfg._M_ivf: counts the IVF step) */
+  int32_t K;            /* codebook size of every QINCo step */
   int32_t A;            /* candidates pre-selected per beam (0 = all K, QINCo1) */
   int32_t B;            /* beam size */
   int32_t qinco1_mode;  /* 1: res_codeword_coeff = 0 (qinco_inference.py:29) */
-  int32_t reserved;
+  int32_t ivf_K;        /* 0, or IVF-QINCo: step 0 is an IVFBook of ivf_K centroids (multiple of 32, <= 2^24);
+                           beam_0 = 1 and the first QINCo step pre-selects max(A, B) (qinco_base.py:108-112, 128-196) */
   int64_t max_batch;    /* vectors processed per internal pass (scratch is sized for it) */
 } qinco_desc;
 
@@ -69,7 +70,8 @@ typedef struct {
 typedef struct {
   const float* data_mean;           /* (D) */
   float data_std;                   /* () must be > 0 (qinco_base.py:526) */
-  const float* const* codebook;     /* [M] -> (K, D)   steps.m.codebook.weight */
+  const float* const* codebook;     /* [M] -> (K, D)   steps.m.codebook.weight; with ivf_K > 0 entry 0 is
+                                       steps.0.ivf_centroids.weight (ivf_K, D) */
   const float* const* sub_codebook; /* [M] -> (K, D)   steps.m.substep.codebook.weight; NULL entries / NULL if A == 0 */
   const float* const* in_proj;      /* [M] -> (De, D)  steps.m.in_proj.weight;  NULL if De == D */
   const float* const* out_proj;     /* [M] -> (D, De)  steps.m.out_proj.weight; NULL if De == D */

@@ -51,6 +51,10 @@ class StepWeights:
 
     def __init__(self, sd: dict, m: int, L: int):
         p = f"steps.{m}."
+        if m == 0 and p + "ivf_centroids.weight" in sd:  # IVFBook (qinco_base.py:128-196)
+            self.codebook = sd[p + "ivf_centroids.weight"]
+            self.sub_codebook = None
+            return
         self.codebook = sd[p + "codebook.weight"]
         self.sub_codebook = sd.get(p + "substep.codebook.weight")
         if m == 0:
@@ -88,11 +92,13 @@ def step_forward(w: StepWeights, c: np.ndarray, xhat: np.ndarray, qinco1_mode: b
 class OracleQINCo:
     """Oracle twin of QINCoInferenceWrapper (qinco_inference.py:257-353) on the CPU fp32 path."""
 
-    def __init__(self, sd: dict, *, M: int, K: int, L: int, A: int, B: int, qinco1_mode: bool):
+    def __init__(self, sd: dict, *, M: int, K: int, L: int, A: int, B: int, qinco1_mode: bool, ivf: bool = False):
+        """M = number of steps including the IVF step (cfg._M_ivf)."""
         self.sd = {k: np.ascontiguousarray(np.asarray(v, dtype=F32)) for k, v in sd.items()
                    if not k.endswith(("xtarget_mean", "xtarget_var"))}
         self.M, self.K, self.L, self.A, self.B = M, K, L, A, B
         self.qinco1_mode = bool(qinco1_mode)
+        self.ivf = bool(ivf)
         self.data_mean = self.sd["data_mean"]
         self.data_std = F32(self.sd["data_std"])
         assert self.data_std > 0, "data_std must be > 0 (qinco_base.py:526)"
@@ -101,6 +107,11 @@ class OracleQINCo:
         if A > 0 and M > 1 and self.steps[1].sub_codebook is None:
             raise ValueError("Can't evaluate a model trained with A=0 (no candidates pre-selection) "
                              "using a non-zero A value.")  # utils.py:169-172
+
+    @classmethod
+    def from_config(cls, cfg, sd: dict) -> "OracleQINCo":
+        """cfg: any object with M_total, K, L, A, B, qinco1_mode, ivf (qinco_amd.config.QincoConfig)."""
+        return cls(sd, M=cfg.M_total, K=cfg.K, L=cfg.L, A=cfg.A, B=cfg.B, qinco1_mode=cfg.qinco1_mode, ivf=cfg.ivf)
 
     # ---- forward (qinco_inference.py:272-283) ---------------------------------------------------
     def __call__(self, x_in, step: str):
@@ -116,7 +127,8 @@ class OracleQINCo:
     def encode(self, x: np.ndarray, trace: dict | None = None):
         n, D = x.shape
         M, K, A, B = self.M, self.K, self.A, self.B
-        beam_0 = 1 if M == 1 else min(B, K)  # :237 (no IVF); a one-step model must end with one beam
+        K0 = self.steps[0].codebook.shape[0]
+        beam_0 = 1 if (M == 1 or self.ivf) else min(B, K0)  # :237; a one-step model must end with one beam
         d0 = approx_pairwise_distance(x, self.steps[0].codebook)
         codes0 = topk_smallest(d0, beam_0)  # argmin when beam_0 == 1 (:243-245)
         xhat = self.steps[0].codebook[codes0]  # (n, F, D)
@@ -126,7 +138,9 @@ class OracleQINCo:
         for m in range(1, M):
             F_out = B if m < M - 1 else 1  # :152
             if A > 0:
-                xhat, codes = self._step_preselect(self.steps[m], x, xhat, codes, A, F_out, trace, m)
+                # first QINCo step of an IVF model needs max(A, B) candidates (qinco_base.py:108-112)
+                n_codes = max(A, B) if (self.ivf and m == 1) else A
+                xhat, codes = self._step_preselect(self.steps[m], x, xhat, codes, n_codes, F_out, trace, m)
             else:
                 xhat, codes = self._step_all(self.steps[m], x, xhat, codes, F_out, trace, m)
         return codes[:, :, 0].astype(np.int64), xhat[:, 0, :]
@@ -180,8 +194,9 @@ class OracleQINCo:
     def decode(self, codes_MB: np.ndarray) -> np.ndarray:
         codes_MB = np.asarray(codes_MB)
         assert codes_MB.shape[0] == self.M
-        if codes_MB.size and (codes_MB.min() < 0 or codes_MB.max() >= self.K):
-            raise IndexError("code out of range")
+        for m in range(self.M):
+            if codes_MB[m].size and (codes_MB[m].min() < 0 or codes_MB[m].max() >= self.steps[m].codebook.shape[0]):
+                raise IndexError("code out of range")
         xhat = self.steps[0].codebook[codes_MB[0]].copy()
         for m in range(1, self.M):
             w = self.steps[m]

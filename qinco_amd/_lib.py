@@ -23,7 +23,7 @@ API_SYMBOLS = [
 class QincoDesc(C.Structure):
     _fields_ = [("D", C.c_int32), ("De", C.c_int32), ("Dh", C.c_int32), ("L", C.c_int32), ("M", C.c_int32),
                 ("K", C.c_int32), ("A", C.c_int32), ("B", C.c_int32), ("qinco1_mode", C.c_int32),
-                ("reserved", C.c_int32), ("max_batch", C.c_int64)]
+                ("ivf_K", C.c_int32), ("max_batch", C.c_int64)]
 
 
 FP = C.POINTER(C.c_float)

@@ -20,8 +20,6 @@ def config_from_checkpoint(ckpt: dict, A: Optional[int] = None, B: Optional[int]
     if "parameters" not in ckpt:
         raise ValueError("Missing model parameters is acceptable only for converting a model!")  # utils.py:175-177
     p = ckpt["parameters"]
-    if p.get("ivf_in_use"):
-        raise NotImplementedError("IVF-QINCo checkpoints (ivf_in_use) are not supported yet (SURVEY.md 8f1)")
     stored_A = int(p.get("A") or 0)
     if A is not None and A > 0 and not stored_A:
         raise ValueError("Can't evaluate a model trained with A=0 (no candidates pre-selection) "
@@ -29,7 +27,8 @@ def config_from_checkpoint(ckpt: dict, A: Optional[int] = None, B: Optional[int]
     return QincoConfig(D=int(ckpt["data_dim"]), M=int(p["M"]), K=int(p["K"]), L=int(p["L"]),
                        de=(int(p["de"]) if p.get("de") else None), dh=int(p["dh"]),
                        A=stored_A if A is None else int(A), B=int(p.get("B") or 1) if B is None else int(B),
-                       qinco1_mode=bool(p.get("qinco1_mode", False)))
+                       qinco1_mode=bool(p.get("qinco1_mode", False)),
+                       ivf_K=(int(p["ivf_K"]) if p.get("ivf_in_use") and p.get("ivf_K") else None))
 
 
 def state_dict_to_numpy(sd: dict) -> dict:

@@ -20,10 +20,32 @@ class QincoConfig:
     A: int = 0                  # pre-selected candidates (0 = all K)
     B: int = 1                  # beam size
     qinco1_mode: bool = False   # res_codeword_coeff = 0 (qinco_inference.py:29)
+    ivf_K: Optional[int] = None  # IVF-QINCo: step 0 is a frozen coarse codebook of ivf_K centroids (ivf_in_use)
 
     @property
     def De(self) -> int:
         return self.de or self.D
+
+    @property
+    def ivf(self) -> bool:
+        return bool(self.ivf_K)
+
+    @property
+    def M_total(self) -> int:
+        """cfg._M_ivf: columns of the code matrix (IVF id first) (qinco_tasks.py:379-383)."""
+        return self.M + (1 if self.ivf else 0)
+
+    @property
+    def K_vals(self) -> list:
+        """cfg._K_vals."""
+        return ([self.ivf_K] if self.ivf else []) + [self.K] * self.M
+
+    def n_codes(self, m: int) -> int:
+        """Candidates pre-selected at step m: A, or max(A, B) for the first QINCo step of an IVF model
+        (QincoSubstep._n_codes, qinco_base.py:108-112)."""
+        if self.A and self.ivf and m == 1:
+            return max(self.A, self.B)
+        return self.A
 
     def with_search(self, A: Optional[int] = None, B: Optional[int] = None) -> "QincoConfig":
         """CLI-style override of A / B (utils.py:166-172: A > 0 is illegal on an A = 0 model)."""
@@ -40,6 +62,9 @@ class QincoConfig:
              "qinco1_mode": self.qinco1_mode}
         if self.de is not None:
             d["de"] = self.de
+        if self.ivf:
+            d["ivf_in_use"] = True
+            d["ivf_K"] = self.ivf_K
         return d
 
     # algorithmic FLOPs
@@ -50,19 +75,20 @@ class QincoConfig:
         return f
 
     def encode_flops_per_vector(self) -> float:
-        Ae = self.A or self.K
-        total = 2.0 * self.D * self.K
-        F = 1 if self.M == 1 else min(self.B, self.K)
-        for m in range(1, self.M):
+        Mt = self.M_total
+        total = 2.0 * self.D * self.K_vals[0]
+        F = 1 if (Mt == 1 or self.ivf) else min(self.B, self.K)
+        for m in range(1, Mt):
+            Ae = self.n_codes(m) or self.K
             total += F * Ae * self.mlp_flops_per_row()
             if self.A:
                 total += F * self.K * 2.0 * self.D
             total += F * Ae * 2.0 * self.D
-            F = min(self.B if m < self.M - 1 else 1, F * Ae)
+            F = min(self.B if m < Mt - 1 else 1, F * Ae)
         return total
 
     def decode_flops_per_vector(self) -> float:
-        return (self.M - 1) * self.mlp_flops_per_row()
+        return (self.M_total - 1) * self.mlp_flops_per_row()
 
 
 def preset(name: str, D: int, M: int = 8, **over) -> QincoConfig:
@@ -74,7 +100,7 @@ def preset(name: str, D: int, M: int = 8, **over) -> QincoConfig:
         "qinco2-L": dict(L=16, de=384, dh=384, A=16, B=32),
     }[name]
     base.update(over)
-    return QincoConfig(D=D, M=M, K=256, **base)
+    return QincoConfig(D=D, M=M, K=256, **base)   # `over` may carry ivf_K (IVF-qinco2_* models)
 
 
 # The BASELINE.json configs (SURVEY.md section 8 constants).

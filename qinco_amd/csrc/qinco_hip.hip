@@ -13,6 +13,7 @@
 
 #include "../../include/qinco_hip.h"
 #include "aux_kernels.hpp"
+#include "ivf_kernel.hpp"
 #include "mlp_args.hpp"
 #include "mlp_launch.hpp"
 
@@ -82,6 +83,10 @@ struct qinco_handle_s {
   std::vector<f32x4*> wstream;
   int* kvals = nullptr;
   int* err_flag = nullptr;
+  // IVF step 0
+  int K0 = 0;                       // rows of codebook[0] (ivf_K or K)
+  f32x4* ivf_stream = nullptr;      // centroids packed as MFMA A-operand fragments
+  unsigned long long* ivf_best = nullptr;  // (max_batch) merged (distance, id) keys
 
   // scratch (sized for d.max_batch, A, B)
   int64_t cap_n = 0;
@@ -113,6 +118,12 @@ struct qinco_handle_s {
 
   std::vector<void*> owned;  // every device allocation, for destroy
 };
+
+// candidates pre-selected at step m (QincoSubstep._n_codes, qinco_base.py:108-112)
+static int n_codes(const qinco_handle_s* h, int m) {
+  if (h->A > 0 && h->d.ivf_K > 0 && m == 1) return h->A > h->B ? h->A : h->B;
+  return h->A;
+}
 
 static double mlp_flops_per_row(const qinco_desc& d) {
   // R_mlp = [De != D] 4 D De + 2 (De + D) De + 4 L De Dh
@@ -209,15 +220,18 @@ static int upload_with_norms(qinco_handle_s* h, const float* cb, int K, int D, f
 static int ensure_scratch(qinco_handle_s* h) {
   const qinco_desc& d = h->d;
   if (h->cap_n == d.max_batch && h->cap_A == h->A && h->cap_B == h->B) return 0;
-  void* old[] = {h->xn, h->xhat[0], h->xhat[1], h->hist[0], h->hist[1], h->top_ids, h->cand, h->dist};
+  void* old[] = {h->xn, h->xhat[0], h->xhat[1], h->hist[0], h->hist[1], h->top_ids, h->cand, h->dist, h->ivf_best};
   HIP_TRY(hipDeviceSynchronize());
   for (void* p : old) dev_free(h, p);
   h->xn = h->xhat[0] = h->xhat[1] = h->cand = h->dist = nullptr;
   h->hist[0] = h->hist[1] = h->top_ids = nullptr;
+  h->ivf_best = nullptr;
   h->cap_n = 0;
   const size_t n = (size_t)d.max_batch;
   const size_t Bm = (size_t)(h->B < d.K ? h->B : d.K);   // widest beam (beam_0 = min(B, K))
-  const size_t Ae = (size_t)(h->A > 0 ? h->A : d.K);     // candidates per beam
+  size_t Ae = (size_t)(h->A > 0 ? h->A : d.K);           // candidates per beam
+  if (d.ivf_K > 0 && h->A > 0 && (size_t)h->B > Ae) Ae = (size_t)h->B;  // first QINCo step of an IVF model
+  if (Ae > (size_t)d.K) Ae = (size_t)d.K;
   int rc = 0;
   if ((rc = dev_alloc(h, &h->xn, n * d.D))) return rc;
   for (int i = 0; i < 2; ++i) {
@@ -227,6 +241,7 @@ static int ensure_scratch(qinco_handle_s* h) {
   if ((rc = dev_alloc(h, &h->top_ids, n * Bm * (Ae > Bm ? Ae : Bm)))) return rc;
   if ((rc = dev_alloc(h, &h->cand, n * Bm * Ae * d.D))) return rc;
   if ((rc = dev_alloc(h, &h->dist, n * Bm * Ae))) return rc;
+  if (d.ivf_K > 0 && (rc = dev_alloc(h, &h->ivf_best, n))) return rc;
   h->cap_n = d.max_batch;
   h->cap_A = h->A;
   h->cap_B = h->B;
@@ -272,6 +287,11 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
     return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: D, De, Dh must be multiples of 32 (got %d, %d, %d)", d.D, d.De, d.Dh);
   if (d.K > 1024) return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: K=%d > 1024 not supported", d.K);
   if (d.A < 0 || d.A > d.K || d.B < 1) return fail(QINCO_ERR_INVALID, "qinco_create: need 0 <= A <= K and B >= 1");
+  if (d.ivf_K < 0 || d.ivf_K % 32 || d.ivf_K > (1 << 24))
+    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: ivf_K=%d must be a multiple of 32 and <= 2^24", d.ivf_K);
+  if (d.ivf_K > 0 && d.M < 2) return fail(QINCO_ERR_INVALID, "qinco_create: an IVF model needs at least one QINCo step");
+  if (d.ivf_K > 0 && d.D != 32 && d.D != 96 && d.D != 128 && d.D != 256 && d.D != 768)
+    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: no IVF kernel instance for D=%d", d.D);
   if (!(w->data_std > 0.f)) return fail(QINCO_ERR_INVALID, "qinco_create: data_std must be > 0 (qinco_base.py:526)");
   int want_P = -1, want_var = -1;  // A/B hook: QINCO_MLP_VARIANT="P,VAR" selects a non-production instance
   if (const char* ev = getenv("QINCO_MLP_VARIANT")) sscanf(ev, "%d,%d", &want_P, &want_var);
@@ -308,7 +328,9 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   h->cnorm.assign(d.M, nullptr);
   h->sub_cnorm.assign(d.M, nullptr);
   h->wstream.assign(d.M, nullptr);
+  h->K0 = d.ivf_K > 0 ? d.ivf_K : d.K;
   std::vector<int> kv(d.M, d.K);
+  kv[0] = h->K0;
   if ((rc = dev_alloc(h, &h->kvals, d.M))) return bail(rc);
   if (hipMemcpy(h->kvals, kv.data(), d.M * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
     return bail(fail(QINCO_ERR_HIP, "hipMemcpy(kvals) failed"));
@@ -317,8 +339,20 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
 
   for (int m = 0; m < d.M; ++m) {
     if (!w->codebook[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: codebook[%d] is null", m));
-    if ((rc = upload_with_norms(h, w->codebook[m], d.K, d.D, &h->codebook[m], &h->cnorm[m]))) return bail(rc);
-    if (m == 0) continue;
+    if ((rc = upload_with_norms(h, w->codebook[m], m == 0 ? h->K0 : d.K, d.D, &h->codebook[m], &h->cnorm[m]))) return bail(rc);
+    if (m == 0) {
+      if (d.ivf_K > 0) {  // centroids in MFMA fragment order: (block of 32 centroids, feature block, q) -> 1 KiB
+        std::vector<float> s;
+        s.reserve((size_t)d.ivf_K * d.D);
+        for (int cb = 0; cb < d.ivf_K / 32; ++cb)
+          for (int ib = 0; ib < d.D / 32; ++ib)
+            for (int q = 0; q < 4; ++q) put_frag(s, w->codebook[0], d.D, cb, ib, q);
+        float* ds = nullptr;
+        if ((rc = upload(h, &ds, s.data(), s.size()))) return bail(rc);
+        h->ivf_stream = reinterpret_cast<f32x4*>(ds);
+      }
+      continue;
+    }
     if (d.A > 0) {
       if (!w->sub_codebook[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: sub_codebook[%d] is null", m));
       if ((rc = upload_with_norms(h, w->sub_codebook[m], d.K, d.D, &h->sub_codebook[m], &h->sub_cnorm[m]))) return bail(rc);
@@ -423,6 +457,37 @@ static int launch_dist_topk(qinco_handle_s* h, const float* x, const float* xhat
   return 0;
 }
 
+template <int D>
+static void launch_ivf_inst(qinco_handle_s* h, long n, int nblocks, int bps, int slices, hipStream_t st) {
+  hipLaunchKernelGGL(ivf_assign_kernel<D>, dim3((unsigned)((n + 127) / 128), (unsigned)slices), dim3(256), 0, st,
+                     h->ivf_stream, h->cnorm[0], nblocks, bps, h->xn, n, h->ivf_best);
+}
+
+// IVF step 0: codes0 = argmin over the ivf_K centroids (IVFBook.quantize, qinco_base.py:146-163) -> top_ids[n]
+static int launch_ivf_assign(qinco_handle_s* h, long n, hipStream_t st) {
+  const qinco_desc& d = h->d;
+  const int nblocks = d.ivf_K / 32;
+  const long tiles = (n + 127) / 128;
+  long slices = (2048 + tiles - 1) / tiles;  // aim at >= 2048 workgroups (8 per CU: low-register kernel)
+  if (slices > nblocks) slices = nblocks;
+  if (slices < 1) slices = 1;
+  const int bps = (int)((nblocks + slices - 1) / slices);
+  slices = (nblocks + bps - 1) / bps;
+  HIP_TRY(hipMemsetAsync(h->ivf_best, 0xFF, (size_t)n * sizeof(unsigned long long), st));
+  switch (d.D) {
+    case 32: launch_ivf_inst<32>(h, n, nblocks, bps, (int)slices, st); break;
+    case 96: launch_ivf_inst<96>(h, n, nblocks, bps, (int)slices, st); break;
+    case 128: launch_ivf_inst<128>(h, n, nblocks, bps, (int)slices, st); break;
+    case 256: launch_ivf_inst<256>(h, n, nblocks, bps, (int)slices, st); break;
+    case 768: launch_ivf_inst<768>(h, n, nblocks, bps, (int)slices, st); break;
+    default: return fail(QINCO_ERR_UNSUPPORTED, "no IVF kernel instance for D=%d", d.D);
+  }
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(ivf_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->ivf_best, n, h->top_ids);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t stride, int64_t n, void* codes_out,
                         int code_dtype, float* xhat_out, int flags, hipStream_t st) {
   const qinco_desc& d = h->d;
@@ -430,21 +495,27 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
   hipLaunchKernelGGL(normalize_kernel, dim3(ew_grid(n * D)), dim3(256), 0, st, x, x_dtype, (long)stride,
                      (flags & QINCO_FLAG_NORMALISED) ? (const float*)nullptr : h->mean, h->std_, h->xn, (long)n, D);
   HIP_TRY(hipGetLastError());
-  // step 0: plain codebook, beam_0 = min(B, K0)  (qinco_inference.py:237-246); a single-step model ends at F = 1
-  int F = (M == 1) ? 1 : (B < K ? B : K);
+  // step 0: plain codebook, beam_0 = min(B, K0), or 1 with IVF (qinco_inference.py:237-246); a single-step model
+  // ends at F = 1
+  int F = (M == 1 || d.ivf_K > 0) ? 1 : (B < K ? B : K);
   int rc;
-  if ((rc = launch_dist_topk(h, h->xn, nullptr, 1, h->codebook[0], h->cnorm[0], n, F, h->top_ids, st))) return rc;
+  if (d.ivf_K > 0) {
+    if ((rc = launch_ivf_assign(h, n, st))) return rc;
+  } else if ((rc = launch_dist_topk(h, h->xn, nullptr, 1, h->codebook[0], h->cnorm[0], n, F, h->top_ids, st))) {
+    return rc;
+  }
   int cur = 0;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(n * F * (D / 4))), dim3(256), 0, st, h->codebook[0], h->top_ids,
                      (long)n * F, D, h->xhat[cur], h->hist[cur], M);
   HIP_TRY(hipGetLastError());
   for (int m = 1; m < M; ++m) {
     const int Fout_cfg = (m < M - 1) ? B : 1;  // qinco_inference.py:152
-    const int Ae = A > 0 ? A : K;
+    const int Am = n_codes(h, m) < K ? n_codes(h, m) : K;
+    const int Ae = A > 0 ? Am : K;
     const long G = (long)n * F;
     const int* cand_ids = nullptr;
     if (A > 0) {
-      if ((rc = launch_dist_topk(h, h->xn, h->xhat[cur], F, h->sub_codebook[m], h->sub_cnorm[m], G, A, h->top_ids, st)))
+      if ((rc = launch_dist_topk(h, h->xn, h->xhat[cur], F, h->sub_codebook[m], h->sub_cnorm[m], G, Am, h->top_ids, st)))
         return rc;
       cand_ids = h->top_ids;
     }
@@ -489,7 +560,8 @@ static int check_common(qinco_handle h, const void* a, const void* b, int64_t n,
   if (n < 0) return fail(QINCO_ERR_INVALID, "%s: n < 0", who);
   if (n > 0 && (!a || !b)) return fail(QINCO_ERR_INVALID, "%s: null buffer", who);
   if (code_dtype < 0 || code_dtype > 2) return fail(QINCO_ERR_INVALID, "%s: bad code dtype %d", who, code_dtype);
-  if (code_dtype == QINCO_CODE_U8 && h->d.K > 256) return fail(QINCO_ERR_INVALID, "%s: uint8 codes need K <= 256", who);
+  if (code_dtype == QINCO_CODE_U8 && (h->d.K > 256 || h->d.ivf_K > 256))
+    return fail(QINCO_ERR_INVALID, "%s: uint8 codes need K <= 256 (and no IVF column)", who);
   return 0;
 }
 
@@ -651,11 +723,11 @@ extern "C" int qinco_profile_read(qinco_handle h, double* mlp_ms, int64_t* mlp_l
 extern "C" double qinco_flops_per_vector_encode(qinco_handle h) {
   if (!h) return 0.0;
   const qinco_desc& d = h->d;
-  const double Ae = h->A > 0 ? h->A : d.K;
   const double rm = mlp_flops_per_row(d);
-  double total = 2.0 * d.D * d.K;  // step 0 table
-  int F = (d.M == 1) ? 1 : (h->B < d.K ? h->B : d.K);
+  double total = 2.0 * d.D * (d.ivf_K > 0 ? d.ivf_K : d.K);  // step 0 table
+  int F = (d.M == 1 || d.ivf_K > 0) ? 1 : (h->B < d.K ? h->B : d.K);
   for (int m = 1; m < d.M; ++m) {
+    const double Ae = h->A > 0 ? n_codes(h, m) : d.K;
     total += F * Ae * rm;                              // MLP
     if (h->A > 0) total += (double)F * d.K * 2.0 * d.D;  // pre-selection table
     total += F * Ae * 2.0 * d.D;                        // candidate distances

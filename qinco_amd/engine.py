@@ -53,7 +53,7 @@ class QincoEngine:
         def parr(n):
             return (_lib.FP * n)()
 
-        M, L, K, D, De, Dh = cfg.M, cfg.L, cfg.K, cfg.D, cfg.De, cfg.dh
+        M, L, K, D, De, Dh = cfg.M_total, cfg.L, cfg.K, cfg.D, cfg.De, cfg.dh
         w = _lib.QincoWeights()
         w.data_mean = ptr("data_mean", (D,))
         std = float(np.asarray(sd["data_std"]).reshape(-1)[0]) if "data_std" in sd else 0.0
@@ -62,6 +62,9 @@ class QincoEngine:
         up, down = parr(max(M * L, 1)), parr(max(M * L, 1))
         for m in range(M):
             p = f"steps.{m}."
+            if m == 0 and cfg.ivf:      # IVFBook (qinco_base.py:128-196)
+                cb[0] = ptr(p + "ivf_centroids.weight", (cfg.ivf_K, D))
+                continue
             cb[m] = ptr(p + "codebook.weight", (K, D))
             if m == 0:
                 continue
@@ -78,7 +81,7 @@ class QincoEngine:
         w.codebook, w.sub_codebook, w.in_proj, w.out_proj = cb, sub, inp, outp
         w.cat_w, w.cat_b, w.up, w.down = cw, cbias, up, down
         desc = _lib.QincoDesc(D=D, De=De, Dh=Dh, L=L, M=M, K=K, A=cfg.A, B=cfg.B,
-                              qinco1_mode=int(cfg.qinco1_mode), reserved=0, max_batch=self.max_batch)
+                              qinco1_mode=int(cfg.qinco1_mode), ivf_K=int(cfg.ivf_K or 0), max_batch=self.max_batch)
         _lib.check(self.lib.qinco_create(C.byref(desc), C.byref(w), C.byref(self._h)))
         self._keep = []  # weights now live on the device
         self.data_mean = sd["data_mean"]
@@ -108,7 +111,7 @@ class QincoEngine:
         """x: (n, D) float32 / uint8, numpy (host path) or torch CUDA tensor (device path, async on the current
         stream).  Returns codes (n, M) [and the normalised reconstruction (n, D)].  normalised=True: x is already
         (x - mean) / std, i.e. QINCoInferenceWrapper.encode instead of forward."""
-        M, D = self.cfg.M, self.cfg.D
+        M, D = self.cfg.M_total, self.cfg.D
         flags = _lib.FLAG_NORMALISED if normalised else 0
         if _is_torch(x) and x.is_cuda:
             import torch
@@ -149,7 +152,7 @@ class QincoEngine:
     def decode(self, codes, normalised: bool = False):
         """codes: (n, M) int64 / int32 / uint8, numpy or torch CUDA tensor.  Returns (n, D) float32, denormalised
         (forward(step="decode")) unless normalised=True (QINCoInferenceWrapper.decode)."""
-        M, D = self.cfg.M, self.cfg.D
+        M, D = self.cfg.M_total, self.cfg.D
         flags = _lib.FLAG_NORMALISED if normalised else 0
         if _is_torch(codes) and codes.is_cuda:
             import torch

@@ -65,7 +65,9 @@ class QINCoHIP:
     def get_codebooks_refs(self):
         """qinco_base.py:541-549: per step, [codebook] (+ [substep codebook])."""
         refs = []
-        for m in range(self.cfg.M):
+        for m in range(self.cfg.M_total):
+            if m == 0 and self.cfg.ivf:
+                continue    # IVFBook steps are skipped by the reference (qinco_base.py:544)
             r = [self._sd[f"steps.{m}.codebook.weight"]]
             k = f"steps.{m}.substep.codebook.weight"
             if k in self._sd:

@@ -24,8 +24,12 @@ def synth_state_dict(cfg: QincoConfig, seed: int = 1234, gain: float = 0.6,
     def lin(o, i):
         return (rs.randn(o, i) * (gain / np.sqrt(i))).astype(F32)
 
-    for m in range(cfg.M):
+    for m in range(cfg.M_total):
         p = f"steps.{m}."
+        if m == 0 and cfg.ivf:
+            # IVFBook (qinco_base.py:128-196): a frozen coarse codebook, already in normalised space
+            sd[p + "ivf_centroids.weight"] = rs.randn(cfg.ivf_K, D).astype(F32)
+            continue
         cb = (rs.randn(cfg.K, D) * (0.6 ** m)).astype(F32)
         sd[p + "codebook.weight"] = cb
         sd[p + "xtarget_mean"] = np.zeros(D, F32)   # training buffers, unused at inference
@@ -58,4 +62,4 @@ def synth_vectors(cfg: QincoConfig, sd: dict, n: int, seed: int = 42) -> np.ndar
 def synth_codes(cfg: QincoConfig, n: int, seed: int = 7) -> np.ndarray:
     """Uniform random codes (M, n) int64 for decode tests / the structured S1 inputs."""
     rs = np.random.RandomState(seed)
-    return rs.randint(0, cfg.K, size=(cfg.M, n)).astype(np.int64)
+    return np.stack([rs.randint(0, k, size=n) for k in cfg.K_vals]).astype(np.int64)

@@ -27,6 +27,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, "/root/reference")
 
 from qinco.model import QINCo, QINCoInferenceWrapper  # noqa: E402  (the reference)
+from qinco.model.qinco_base import IVFBook  # noqa: E402
 
 from qinco_amd.config import QincoConfig, preset  # noqa: E402
 from qinco_amd.synth import synth_codes, synth_state_dict, synth_vectors  # noqa: E402
@@ -46,15 +47,17 @@ class Acc:
 
 
 def ref_cfg(cfg: QincoConfig, batch: int = 64):
-    return NS(A=cfg.A, B=cfg.B, K=cfg.K, L=cfg.L, de=cfg.de, dh=cfg.dh, M=cfg.M, _D=cfg.D, _M_ivf=cfg.M,
-              _K_vals=[cfg.K] * cfg.M, _ivf_book=None, qinco1_mode=cfg.qinco1_mode, _qinco_jit=False,
-              _accelerator=Acc(), task="eval", enc_max_bs=65536, ivf_in_use=None, batch=batch,
-              codebook_noise_init=0.1, ivf_K=None, inference=True)
+    return NS(A=cfg.A, B=cfg.B, K=cfg.K, L=cfg.L, de=cfg.de, dh=cfg.dh, M=cfg.M, _D=cfg.D, _M_ivf=cfg.M_total,
+              _K_vals=list(cfg.K_vals), _ivf_book=None, qinco1_mode=cfg.qinco1_mode, _qinco_jit=False,
+              _accelerator=Acc(), task="eval", enc_max_bs=65536, ivf_in_use=(True if cfg.ivf else None), batch=batch,
+              codebook_noise_init=0.1, ivf_K=cfg.ivf_K, inference=True)
 
 
 def build_reference(cfg: QincoConfig, sd: dict):
     rc = ref_cfg(cfg)
     with torch.no_grad():
+        if cfg.ivf:  # initialize_model: cfg._ivf_book = IVFBook(cfg, centroids) (qinco_tasks.py:277-285)
+            rc._ivf_book = IVFBook(rc, np.asarray(sd["steps.0.ivf_centroids.weight"]))
         model = QINCo(rc)
         missing = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
         assert not missing.missing_keys and not missing.unexpected_keys
@@ -76,13 +79,17 @@ CASES = {
     "C2_qinco2L_8x8_b8": (preset("qinco2-L", D=128, M=8, B=8), 1236, 64),
     "C2_qinco2L_8x8_b1": (preset("qinco2-L", D=128, M=8, B=1), 1236, 64),
     "C4_qinco2L_d768_b8": (preset("qinco2-L", D=768, M=4, B=8), 1238, 32),
+    # IVF-QINCo: coarse step of ivf_K centroids, beam_0 = 1, first QINCo step takes max(A, B)
+    "tiny_ivf_beam": (QincoConfig(D=32, M=3, K=256, L=2, de=64, dh=96, A=4, B=8, ivf_K=2048), 15, 256),
+    "tiny_ivf_greedy_id": (QincoConfig(D=32, M=3, K=256, L=2, de=None, dh=64, A=8, B=1, ivf_K=1024), 16, 256),
+    "ivf_qinco2S_d128": (preset("qinco2-S", D=128, M=4, B=8, ivf_K=65536), 1240, 64),
 }
 
 
 def run_case(name: str, cfg: QincoConfig, seed: int, n: int) -> dict:
     sd = synth_state_dict(cfg, seed)
     model, wrapper = build_reference(cfg, sd)
-    oracle = OracleQINCo(sd, M=cfg.M, K=cfg.K, L=cfg.L, A=cfg.A, B=cfg.B, qinco1_mode=cfg.qinco1_mode)
+    oracle = OracleQINCo.from_config(cfg, sd)
 
     x0 = synth_vectors(cfg, sd, n, seed=seed + 1)
     # S1 "structured" half: x = decode(random codes) + small noise, so that beams really compete
@@ -121,13 +128,16 @@ def run_case(name: str, cfg: QincoConfig, seed: int, n: int) -> dict:
     codes_ref = out.get("codes_wrapper", out["codes_base"])
     agree = float((codes_o.T == codes_ref).all(axis=1).mean())
     margins = []
-    for m in range(1, cfg.M):
+    for m in range(1, cfg.M_total):
         d = np.sort(trace[f"dists{m}"], axis=-1)
-        fo = min(cfg.B if m < cfg.M - 1 else 1, d.shape[1] - 1)
+        fo = min(cfg.B if m < cfg.M_total - 1 else 1, d.shape[1] - 1)
         margins.append((d[:, fo] - d[:, fo - 1]) / np.maximum(np.abs(d[:, fo]), 1e-12))
         if f"top{m}" in trace:
             out[f"oracle_top{m}"] = trace[f"top{m}"].astype(np.int16)
-    out["select_rel_margin"] = np.stack(margins, axis=1).astype(np.float32)  # (N, M-1)
+    if cfg.ivf:  # margin of the coarse assignment (step 0)
+        d0 = np.sort(trace["d0"], axis=-1)
+        out["ivf_rel_margin"] = ((d0[:, 1] - d0[:, 0]) / np.maximum(np.abs(d0[:, 1]), 1e-12)).astype(np.float32)
+    out["select_rel_margin"] = np.stack(margins, axis=1).astype(np.float32)  # (N, M_total-1)
     mse_ref = float(((x - dec) ** 2).sum(-1).mean())
     out["mse"] = np.float64(mse_ref)
     print(f"{name:24s} N={len(x):4d} wrapper==base: "

@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4"])
     ap.add_argument("--batch", type=int, default=16384, help="vectors per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one GPU per rank). gloo is a test hook: ranks may share a GPU.")
     args = ap.parse_args()
 
     import torch
@@ -86,11 +88,19 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but only {ndev} GPU(s): RCCL needs one GPU per rank")
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
     from qinco_amd.config import BASELINE_CONFIGS
@@ -105,8 +115,12 @@ def main():
     K = args.steps
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
@@ -121,15 +135,18 @@ def main():
         codes_steps.append(eng.encode(x, code_dtype=np.uint8))
     mine = torch.stack(codes_steps) if K else torch.empty(0, dtype=torch.uint8, device=dev)
     if world > 1:  # the end-of-job gather of the uint8 codes over RCCL / xGMI
-        bucket = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, bucket, dst=0)
+        mine_c = mine.to(comm_dev)
+        bucket = [torch.empty_like(mine_c) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine_c, bucket, dst=0)
+        if rank == 0:
+            assert len(bucket) == world and all(b.shape == mine_c.shape for b in bucket)
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(False)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -109,4 +109,7 @@ BASELINE_CONFIGS = {
     "C2": preset("qinco2-L", D=128, M=8, B=8),
     "C3": preset("qinco2-L", D=128, M=16, B=8),
     "C4": preset("qinco2-L", D=768, M=8, B=8),
+    # IVF-qinco2 models of the reference's large-scale search (README "IVF-qinco2_*"), ivf_K = 2^20
+    "IVF_L": preset("qinco2-L", D=128, M=8, B=8, ivf_K=1 << 20),
+    "IVF_S": preset("qinco2-S", D=128, M=8, B=8, ivf_K=1 << 20),
 }

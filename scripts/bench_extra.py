@@ -40,7 +40,8 @@ def main():
                     continue
                 nvec = args.batch if mode == "encode" else args.batch * 16
                 codes = torch.from_numpy(synth_codes(cfg0, nvec, seed=9).T.copy()).to(dev)
-                fn = (lambda: eng.encode(x, code_dtype=np.uint8)) if mode == "encode" else (lambda: eng.decode(codes))
+                cdt = np.int32 if cfg0.ivf else np.uint8
+                fn = (lambda: eng.encode(x, code_dtype=cdt)) if mode == "encode" else (lambda: eng.decode(codes))
                 fn()
                 torch.cuda.synchronize()
                 eng.profile_enable(True)

@@ -97,4 +97,129 @@ __global__ void ivf_finish_kernel(const unsigned long long* __restrict__ best, l
   if (i < N) ids[i] = (int)(best[i] & 0xffffffffu);
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1+K2 on the matrix cores: the residual -> codebook table of dist_topk_kernel (aux_kernels.hpp) for K = 32*NKB
+// codewords, evaluated like the IVF table (a wave = 32 groups as B operands, codebook fragments as A operands),
+// written to a wave-private LDS table [32 groups][K (+4 pad)] and reduced by the same T rounds of wave64
+// shuffle arg-min.  r = x - xhat is formed on load (blocks are streamed, so any D fits), |r|^2 on the fly.
+// The VALU version spent 6x longer on the table than on the selection (profiles: 621 us per 65 536 groups).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_argmin2(float& v, int& i) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(v, off);
+    const int oi = __shfl_xor(i, off);
+    const bool take = (ov < v) || (ov == v && oi < i);
+    v = take ? ov : v;
+    i = take ? oi : i;
+  }
+}
+
+template <int D, int NKB>
+__global__ void __launch_bounds__(256)
+dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xhat, int F,
+                      const f32x4* __restrict__ cstream, const float* __restrict__ cnorm, long G, int T,
+                      int* __restrict__ ids_out) {
+  constexpr int NDB = D / 32, K = NKB * 32, LDK = K + 4;
+  __shared__ __attribute__((aligned(16))) float table[4 * 32 * LDK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, half = lane >> 5;
+  const long g0 = ((long)blockIdx.x * 4 + wave) * 32;
+  if (g0 >= G) return;  // wave-uniform; only wave-level ordering below
+  long g = g0 + j;
+  if (g >= G) g = G - 1;
+  const float* xp = x + (g / F) * D + half * 4;
+  const float* hp = xhat ? xhat + g * D + half * 4 : nullptr;
+  const f32x4* wp = cstream + lane;
+  f32x16 acc[NKB];
+#pragma unroll
+  for (int cb = 0; cb < NKB; ++cb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+  float rn = 0.f;
+#pragma unroll
+  for (int ib = 0; ib < NDB; ++ib) {
+    f32x16 rb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(xp + ib * 32 + 8 * q);
+      if (hp) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(hp + ib * 32 + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = __fsub_rn(t[e], u[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        rb[4 * q + e] = t[e];
+        rn = fmaf(t[e], t[e], rn);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int cb = 0; cb < NKB; ++cb) {
+        const f32x4 w = wp[((cb * NDB + ib) * 4 + q) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], rb[4 * q + e], acc[cb], 0, 0, 0);
+      }
+  }
+  rn += __shfl_xor(rn, 32);
+  float* mytab = table + wave * 32 * LDK;
+  float* row = mytab + j * LDK;
+#pragma unroll
+  for (int cb = 0; cb < NKB; ++cb)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int k = cb * 32 + 8 * gq + 4 * half;
+      const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + k);
+      f32x4 d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = __fsub_rn(__fadd_rn(rn, cn[e]), __fmul_rn(2.f, acc[cb][4 * gq + e]));
+      *reinterpret_cast<f32x4*>(row + k) = d;
+    }
+  __builtin_amdgcn_wave_barrier();
+  // Selection: the T rounds of one group are a chain of dependent cross-lane shuffles (latency-bound), so GP
+  // groups are reduced side by side to give the scheduler independent chains to interleave.
+  constexpr int GP = 4;
+  const int gend = (int)((G - g0) < 32 ? (G - g0) : 32);
+  for (int gl0 = 0; gl0 < gend; gl0 += GP) {
+    for (int t = 0; t < T; ++t) {
+      float bv[GP];
+      int bi[GP];
+#pragma unroll
+      for (int u = 0; u < GP; ++u) {
+        const float* dg = mytab + (gl0 + u < 32 ? gl0 + u : 31) * LDK;
+        bv[u] = __builtin_inff();
+        bi[u] = 0x7fffffff;
+#pragma unroll
+        for (int k = lane; k < K; k += 64) {
+          const float v = dg[k];
+          if (v < bv[u] || (v == bv[u] && k < bi[u])) { bv[u] = v; bi[u] = k; }
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+          const float ov = __shfl_xor(bv[u], off);
+          const int oi = __shfl_xor(bi[u], off);
+          const bool take = (ov < bv[u]) || (ov == bv[u] && oi < bi[u]);
+          bv[u] = take ? ov : bv[u];
+          bi[u] = take ? oi : bi[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GP; ++u) {
+        if (gl0 + u < gend) {
+          int b = bi[u] == 0x7fffffff ? 0 : bi[u];
+          if (lane == 0) ids_out[(g0 + gl0 + u) * T + t] = b;
+          if ((b & 63) == lane) mytab[(gl0 + u) * LDK + b] = __builtin_inff();
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 }  // namespace qinco

@@ -80,6 +80,7 @@ struct qinco_handle_s {
   float* mean = nullptr;
   float std_ = 1.f;
   std::vector<float*> codebook, sub_codebook, cnorm, sub_cnorm;
+  std::vector<f32x4*> cb_stream, sub_stream;   // the same codebooks as MFMA A-operand fragments (table kernels)
   std::vector<f32x4*> wstream;
   int* kvals = nullptr;
   int* err_flag = nullptr;
@@ -118,6 +119,11 @@ struct qinco_handle_s {
 
   std::vector<void*> owned;  // every device allocation, for destroy
 };
+
+// the MFMA table kernel is instantiated for K = 256 and the D of the MLP/IVF instances
+static bool mfma_table_ok(const qinco_desc& d) {
+  return d.K == 256 && (d.D == 32 || d.D == 96 || d.D == 128 || d.D == 256 || d.D == 768);
+}
 
 // candidates pre-selected at step m (QincoSubstep._n_codes, qinco_base.py:108-112)
 static int n_codes(const qinco_handle_s* h, int m) {
@@ -200,6 +206,19 @@ static int upload(qinco_handle_s* h, float** dst, const float* src, size_t count
   if (rc) return rc;
   HIP_TRY(hipMemcpy(*dst, src, count * sizeof(float), hipMemcpyHostToDevice));
   return 0;
+}
+
+// codebook (K, D) in MFMA fragment order: (block of 32 codewords, feature block, q) -> 1 KiB
+static int upload_fragments(qinco_handle_s* h, const float* cb, int K, int D, f32x4** out) {
+  std::vector<float> s;
+  s.reserve((size_t)K * D);
+  for (int kb = 0; kb < K / 32; ++kb)
+    for (int ib = 0; ib < D / 32; ++ib)
+      for (int q = 0; q < 4; ++q) put_frag(s, cb, D, kb, ib, q);
+  float* ds = nullptr;
+  int rc = upload(h, &ds, s.data(), s.size());
+  *out = reinterpret_cast<f32x4*>(ds);
+  return rc;
 }
 
 static int upload_with_norms(qinco_handle_s* h, const float* cb, int K, int D, float** d_cb, float** d_norm) {
@@ -328,6 +347,8 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   h->cnorm.assign(d.M, nullptr);
   h->sub_cnorm.assign(d.M, nullptr);
   h->wstream.assign(d.M, nullptr);
+  h->cb_stream.assign(d.M, nullptr);
+  h->sub_stream.assign(d.M, nullptr);
   h->K0 = d.ivf_K > 0 ? d.ivf_K : d.K;
   std::vector<int> kv(d.M, d.K);
   kv[0] = h->K0;
@@ -341,21 +362,17 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
     if (!w->codebook[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: codebook[%d] is null", m));
     if ((rc = upload_with_norms(h, w->codebook[m], m == 0 ? h->K0 : d.K, d.D, &h->codebook[m], &h->cnorm[m]))) return bail(rc);
     if (m == 0) {
-      if (d.ivf_K > 0) {  // centroids in MFMA fragment order: (block of 32 centroids, feature block, q) -> 1 KiB
-        std::vector<float> s;
-        s.reserve((size_t)d.ivf_K * d.D);
-        for (int cb = 0; cb < d.ivf_K / 32; ++cb)
-          for (int ib = 0; ib < d.D / 32; ++ib)
-            for (int q = 0; q < 4; ++q) put_frag(s, w->codebook[0], d.D, cb, ib, q);
-        float* ds = nullptr;
-        if ((rc = upload(h, &ds, s.data(), s.size()))) return bail(rc);
-        h->ivf_stream = reinterpret_cast<f32x4*>(ds);
+      if (d.ivf_K > 0) {
+        if ((rc = upload_fragments(h, w->codebook[0], d.ivf_K, d.D, &h->ivf_stream))) return bail(rc);
+      } else if (mfma_table_ok(d)) {
+        if ((rc = upload_fragments(h, w->codebook[0], d.K, d.D, &h->cb_stream[0]))) return bail(rc);
       }
       continue;
     }
     if (d.A > 0) {
       if (!w->sub_codebook[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: sub_codebook[%d] is null", m));
       if ((rc = upload_with_norms(h, w->sub_codebook[m], d.K, d.D, &h->sub_codebook[m], &h->sub_cnorm[m]))) return bail(rc);
+      if (mfma_table_ok(d) && (rc = upload_fragments(h, w->sub_codebook[m], d.K, d.D, &h->sub_stream[m]))) return bail(rc);
     }
     // packed stream, in the order mlp_kernel consumes it
     const StreamDims& sd = h->sd;
@@ -447,9 +464,27 @@ static int launch_mlp(qinco_handle_s* h, const MlpArgs& a, hipStream_t st) {
   return 0;
 }
 
+template <int D>
+static void launch_table_inst(const float* x, const float* xhat, int F, const f32x4* cs, const float* cn, long G, int T,
+                              int* ids, hipStream_t st) {
+  hipLaunchKernelGGL((dist_topk_mfma_kernel<D, 8>), dim3((unsigned)((G + 127) / 128)), dim3(256), 0, st, x, xhat, F, cs, cn,
+                     G, T, ids);
+}
+
 static int launch_dist_topk(qinco_handle_s* h, const float* x, const float* xhat, int F, const float* cb,
-                            const float* cn, long G, int T, int* ids, hipStream_t st) {
+                            const f32x4* cstream, const float* cn, long G, int T, int* ids, hipStream_t st) {
   const qinco_desc& d = h->d;
+  if (cstream && !getenv("QINCO_TABLE_VALU")) {
+    switch (d.D) {
+      case 32: launch_table_inst<32>(x, xhat, F, cstream, cn, G, T, ids, st); break;
+      case 96: launch_table_inst<96>(x, xhat, F, cstream, cn, G, T, ids, st); break;
+      case 128: launch_table_inst<128>(x, xhat, F, cstream, cn, G, T, ids, st); break;
+      case 256: launch_table_inst<256>(x, xhat, F, cstream, cn, G, T, ids, st); break;
+      default: launch_table_inst<768>(x, xhat, F, cstream, cn, G, T, ids, st); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   size_t lds = ((size_t)DT_TG * d.D + 256 * DT_CP + (size_t)DT_TG * d.K + DT_TG) * sizeof(float);
   unsigned grid = (unsigned)((G + DT_TG - 1) / DT_TG);
   hipLaunchKernelGGL(dist_topk_kernel, dim3(grid), dim3(256), lds, st, x, xhat, F, cb, cn, d.K, d.D, G, T, ids);
@@ -501,7 +536,7 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
   int rc;
   if (d.ivf_K > 0) {
     if ((rc = launch_ivf_assign(h, n, st))) return rc;
-  } else if ((rc = launch_dist_topk(h, h->xn, nullptr, 1, h->codebook[0], h->cnorm[0], n, F, h->top_ids, st))) {
+  } else if ((rc = launch_dist_topk(h, h->xn, nullptr, 1, h->codebook[0], h->cb_stream[0], h->cnorm[0], n, F, h->top_ids, st))) {
     return rc;
   }
   int cur = 0;
@@ -515,7 +550,8 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
     const long G = (long)n * F;
     const int* cand_ids = nullptr;
     if (A > 0) {
-      if ((rc = launch_dist_topk(h, h->xn, h->xhat[cur], F, h->sub_codebook[m], h->sub_cnorm[m], G, Am, h->top_ids, st)))
+      if ((rc = launch_dist_topk(h, h->xn, h->xhat[cur], F, h->sub_codebook[m], h->sub_stream[m], h->sub_cnorm[m], G, Am, h->top_ids,
+                                 st)))
         return rc;
       cand_ids = h->top_ids;
     }

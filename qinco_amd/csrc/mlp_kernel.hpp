@@ -93,12 +93,29 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   constexpr bool LAZY = (VAR & 1) != 0;
   constexpr bool LDSR = (VAR & 4) != 0;
   constexpr bool PINNED = (VAR & 8) != 0;
+  constexpr bool FINE = (VAR & 16) != 0;  // hand-placed interleave of the ring traffic between the 4 MFMAs of a fragment
+  static_assert(!FINE || LDSR, "FINE needs the LDS ring");
+  // DUAL: consecutive fragments of a chain accumulate into two alternating accumulators (summed at the chain end).
+  // The 4 MFMAs of one fragment stay back-to-back on one accumulator (the matrix pipe forwards srcC), but the ring
+  // instructions that follow every fragment then sit between MFMAs on DIFFERENT accumulators: an instruction
+  // between two MFMAs on the SAME accumulator costs ~+43 cycles (MI355X_MICROARCH.md, per-instruction constants),
+  // which was ~12 % of this kernel.
+  constexpr bool DUAL = (VAR & 32) != 0;
+  static_assert(!DUAL || PINNED, "DUAL is implemented on the pinned plan");
+  // SHR: ONE LDS ring per workgroup instead of one per wave.  Issuing a global_load_lds costs the issuing wave
+  // ~20 cycles of matrix-pipe idle wherever it is placed (scripts/ubench/frag_loop.hip: 278 -> 264 cycles per
+  // fragment), and the four waves of a workgroup fetch the same bytes: so wave w DMAs only the fragments = w (mod 4)
+  // and a raw s_barrier every 4 fragments -- after the issuers' counted vmcnt -- publishes the landed group.
+  constexpr bool SHR = (VAR & 64) != 0;
+  static_assert(!SHR || (LDSR && P % 12 == 0 && P / 4 >= 5), "shared ring: P multiple of 12 (3 register sets, 4 issuers)");
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
   const long tile = (long)blockIdx.x * 4 + wave;
-  if (tile * 32 >= a.R) return;  // wave-uniform; no barriers / LDS in this kernel
+  if constexpr (!SHR) {
+    if (tile * 32 >= a.R) return;  // wave-uniform; waves are independent (no barriers)
+  }                                // SHR: every wave runs (barriers); rows past R are clamped and never stored
   long row = tile * 32 + j;
   const bool valid = row < a.R;
   if (!valid) row = a.R - 1;
@@ -119,13 +136,15 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   const f32x4* wp = a.wstream + lane;
   constexpr int NRING = LDSR ? 3 : P;
   f32x4 ring[NRING];
-  __shared__ f32x4 lds_ring[LDSR ? 4 * P * 64 : 1];
+  __shared__ f32x4 lds_ring[LDSR ? (SHR ? 1 : 4) * P * 64 : 1];
   [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  [[maybe_unused]] f32x4* myring = lds_ring + (LDSR ? wave_u * P * 64 : 0);
-  // DMA of fragment T (relative to the current section origin wp) into its ring slot
+  [[maybe_unused]] f32x4* myring = lds_ring + ((LDSR && !SHR) ? wave_u * P * 64 : 0);
+  // DMA of fragment T (relative to the current section origin wp) into its ring slot.  SHR: T is a multiple of 4
+  // and wave w fetches fragment T + w (branch-free: the wave offset is folded into both base pointers).
+  [[maybe_unused]] const int wofs = SHR ? wave_u * 64 : 0;
   auto dma = [&]<int T>() QINCO_LAMBDA {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + T * 64),
-                                     (__attribute__((address_space(3))) void*)(myring + (T % P) * 64), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + wofs + T * 64),
+                                     (__attribute__((address_space(3))) void*)(myring + wofs + (T % P) * 64), 16, 0, 0);
   };
   // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields = "no wait"): the builtin keeps the wait visible to hipcc's
   // own counter bookkeeping (an asm s_waitcnt made it fall back to lgkmcnt(0) everywhere); the empty asm fences
@@ -135,7 +154,14 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
     asm volatile("" ::: "memory");
   };
-  if constexpr (LDSR) {
+  if constexpr (SHR) {
+    // fragments 0 .. P-5 are issued (P/4 - 1 per wave); "<= P/4 - 2 outstanding" = every wave's first one landed
+    static_for<P / 4 - 1>([&]<int i>() QINCO_LAMBDA { dma.template operator()<4 * i>(); });
+    wait_vm.template operator()<P / 4 - 2>();
+    __builtin_amdgcn_s_barrier();
+    ring[0] = myring[lane];
+    ring[1] = myring[64 + lane];
+  } else if constexpr (LDSR) {
     static_assert(P % 3 == 0 && P >= 6 && P <= 39, "LDS ring depth (3 register sets: P must be a multiple of 3)");
     static_for<P - 1>([&]<int i>() QINCO_LAMBDA { dma.template operator()<i>(); });
     wait_vm.template operator()<P - 2>();  // fragment 0 has landed
@@ -154,9 +180,21 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
       // read and the DMA below).  Then refill the slot of fragment T-1 with fragment T+P-1.
       // fragments T, T+1 are in ring[] (3 register sets, read two steps ahead so that the LDS latency hides
       // wherever the scheduler puts the read); fragment T+2's DMA is P-4 DMAs old.
-      wait_vm.template operator()<P - 4>();
-      ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
-      dma.template operator()<T + P - 1>();
+      if constexpr (SHR) {
+        // Before fragment T = 4g every wave has issued g + P/4 - 1 DMAs; "<= P/4 - 3 outstanding" = its first g + 2
+        // landed, so past the barrier fragments <= 4g + 7 are in LDS: covers the reads (<= 4g + 5) of this group.
+        // The refill below overwrites fragment T - 4 <= 4g - 1, which every wave consumed before this barrier.
+        if constexpr ((T & 3) == 0) {
+          wait_vm.template operator()<P / 4 - 3>();
+          __builtin_amdgcn_s_barrier();
+          dma.template operator()<T + P - 4>();
+        }
+        ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
+      } else {
+        wait_vm.template operator()<P - 4>();
+        ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
+        dma.template operator()<T + P - 1>();
+      }
       return ring[T % 3];
     } else {
       f32x4 w = ring[T % P];
@@ -172,6 +210,35 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA(w[e], b[4 * q + e], acc); });
   };
 
+  // One fragment = 4 dependent MFMAs (256 cycles of matrix pipe).  Everything else the fragment needs -- the
+  // counted wait + LDS read of a later fragment, the DMA refill (~60 issue cycles), the chain-epilogue slice
+  // `extra` -- must sit in the three 64-cycle shadows BETWEEN those MFMAs; hipcc clumps them behind the 4th MFMA
+  // (one ~100-cycle gap = ~36 idle pipe cycles per fragment).  FINE pins the placement with sched_barrier(0).
+  auto noop = []() QINCO_LAMBDA {};
+  auto fragmm = [&]<int T, int q>(f32x16& acc, const f32x16& b, auto&& extra) QINCO_LAMBDA {
+    if constexpr (FINE) {
+      const f32x4 w = ring[T % 3];
+      acc = QINCO_MFMA(w[0], b[4 * q + 0], acc);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vm.template operator()<P - 4>();
+      ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
+      __builtin_amdgcn_sched_barrier(0);
+      acc = QINCO_MFMA(w[1], b[4 * q + 1], acc);
+      __builtin_amdgcn_sched_barrier(0);
+      dma.template operator()<T + P - 1>();
+      __builtin_amdgcn_sched_barrier(0);
+      acc = QINCO_MFMA(w[2], b[4 * q + 2], acc);
+      __builtin_amdgcn_sched_barrier(0);
+      extra();
+      __builtin_amdgcn_sched_barrier(0);
+      acc = QINCO_MFMA(w[3], b[4 * q + 3], acc);
+    } else {
+      const f32x4 w = take.template operator()<T>();
+      mfma4.template operator()<q>(acc, w, b);
+      extra();
+    }
+  };
+
   f32x16 z[NEB];
   f32x16 y[NYB];
 
@@ -184,8 +251,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
       if constexpr (ib + 1 < NDB) cb = load_block(cptr + (ib + 1) * 32);
       static_for<4>([&]<int q>() QINCO_LAMBDA {
         static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-          f32x4 w = take.template operator()<(ib * 4 + q) * NEB + ob>();
-          mfma4.template operator()<q>(z[ob], w, cur);
+          fragmm.template operator()<(ib * 4 + q) * NEB + ob, q>(z[ob], cur, noop);
         });
       });
     });
@@ -218,8 +284,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
       }
       static_for<4>([&]<int q>() QINCO_LAMBDA {
         static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-          f32x4 w = take.template operator()<(ib * 4 + q) * NEB + ob>();
-          mfma4.template operator()<q>(y[ob], w, b);
+          fragmm.template operator()<(ib * 4 + q) * NEB + ob, q>(y[ob], b, noop);
         });
       });
     });
@@ -232,45 +297,63 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   if constexpr (PINNED) {
     // Register-file plan (the compiler is told, not asked): z lives in VGPRs (B operand of the up-projection,
     // VALU-updated by the residual add), y lives in AGPRs (B operand of the down-projection, never touched by
-    // VALU after it is written), chain accumulators t[2] are VGPR temporaries.  Epilogues run one chain late:
-    //   up:   y[ob-1] = relu(t_prev)  (16 v_max_i32 + 16 v_accvgpr_write) under chain ob's first MFMAs
-    //   down: z[ob-1] += t_prev       (16 v_add_f32, all-VGPR)            under chain ob's first MFMAs
+    // VALU after it is written), chain accumulators are temporaries.  Epilogues run one chain late:
+    //   up:   y[ob-1] = relu(prev)  (16 v_max_i32 + 16 v_accvgpr_write) under chain ob's first MFMAs
+    //   down: z[ob-1] += prev       (16 v_add_f32, all-VGPR)            under chain ob's first MFMAs
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA { pin_v(z[ob]); });
 #pragma unroll 1
     for (int l = 0; l < a.L; ++l) {
-      f32x16 t[2];
+      f32x16 t[2];     // !DUAL: chain ob accumulates in t[ob&1], t[(ob-1)&1] is the finished previous chain
+      f32x16 prev;     //  DUAL: t[0], t[1] alternate per fragment; prev = their sum for the finished chain
       static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
-        t[ob & 1] = zero16();
+        if constexpr (DUAL) { t[0] = zero16(); t[1] = zero16(); } else { t[ob & 1] = zero16(); }
         static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
           static_for<4>([&]<int q>() QINCO_LAMBDA {
-            f32x4 w = take.template operator()<(ob * NEB + ib) * 4 + q>();
-            mfma4.template operator()<q>(t[ob & 1], w, z[ib]);
+            constexpr int TI = (ob * NEB + ib) * 4 + q;
+            f32x16& acc = t[DUAL ? (TI & 1) : (ob & 1)];
             if constexpr (ib == 0 && ob > 0) {  // a quarter of the previous chain's epilogue per fragment
-              static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob - 1][4 * q + e] = relu1(t[(ob - 1) & 1][4 * q + e]); });
+              fragmm.template operator()<TI, q>(acc, z[ib], [&]() QINCO_LAMBDA {
+                static_for<4>([&]<int e>() QINCO_LAMBDA {
+                  y[ob - 1][4 * q + e] = relu1(DUAL ? prev[4 * q + e] : t[(ob - 1) & 1][4 * q + e]);
+                });
+              });
               if constexpr (q == 3) pin_a(y[ob - 1]);
+            } else {
+              fragmm.template operator()<TI, q>(acc, z[ib], noop);
             }
           });
         });
+        if constexpr (DUAL) prev = t[0] + t[1];
       });
-      relu16(t[(NHB - 1) & 1]);
-      y[NHB - 1] = t[(NHB - 1) & 1];
-      pin_a(y[NHB - 1]);
+      {
+        f32x16& last = DUAL ? prev : t[(NHB - 1) & 1];
+        relu16(last);
+        y[NHB - 1] = last;
+        pin_a(y[NHB - 1]);
+      }
       skip_pad.template operator()<NHB * NEB * 4, SL.T_UP>();
       wp += SL.T_UP * 64;
       static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-        t[ob & 1] = zero16();
+        if constexpr (DUAL) { t[0] = zero16(); t[1] = zero16(); } else { t[ob & 1] = zero16(); }
         static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
           static_for<4>([&]<int q>() QINCO_LAMBDA {
-            f32x4 w = take.template operator()<(ob * NHB + ib) * 4 + q>();
-            mfma4.template operator()<q>(t[ob & 1], w, y[ib]);
+            constexpr int TI = (ob * NHB + ib) * 4 + q;
+            f32x16& acc = t[DUAL ? (TI & 1) : (ob & 1)];
             if constexpr (ib == 0 && ob > 0) {
-              static_for<4>([&]<int e>() QINCO_LAMBDA { z[ob - 1][4 * q + e] += t[(ob - 1) & 1][4 * q + e]; });
+              fragmm.template operator()<TI, q>(acc, y[ib], [&]() QINCO_LAMBDA {
+                static_for<4>([&]<int e>() QINCO_LAMBDA {
+                  z[ob - 1][4 * q + e] += DUAL ? prev[4 * q + e] : t[(ob - 1) & 1][4 * q + e];
+                });
+              });
               if constexpr (q == 3) pin_v(z[ob - 1]);
+            } else {
+              fragmm.template operator()<TI, q>(acc, y[ib], noop);
             }
           });
         });
+        if constexpr (DUAL) prev = t[0] + t[1];
       });
-      z[NEB - 1] = z[NEB - 1] + t[(NEB - 1) & 1];
+      z[NEB - 1] = z[NEB - 1] + (DUAL ? prev : t[(NEB - 1) & 1]);
       pin_v(z[NEB - 1]);
       skip_pad.template operator()<NEB * NHB * 4, SL.T_DOWN>();
       wp += SL.T_DOWN * 64;
@@ -282,8 +365,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
         f32x16 acc = zero16();
         static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
           static_for<4>([&]<int q>() QINCO_LAMBDA {
-            f32x4 w = take.template operator()<(ob * NEB + ib) * 4 + q>();
-            mfma4.template operator()<q>(acc, w, z[ib]);
+            fragmm.template operator()<(ob * NEB + ib) * 4 + q, q>(acc, z[ib], noop);
           });
         });
         relu16(acc);
@@ -295,8 +377,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
         f32x16 acc = zero16();
         static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
           static_for<4>([&]<int q>() QINCO_LAMBDA {
-            f32x4 w = take.template operator()<(ob * NHB + ib) * 4 + q>();
-            mfma4.template operator()<q>(acc, w, y[ib]);
+            fragmm.template operator()<(ob * NHB + ib) * 4 + q, q>(acc, y[ib], noop);
           });
         });
         z[ob] = z[ob] + acc;
@@ -312,8 +393,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
         y[ob] = zero16();
         static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
           static_for<4>([&]<int q>() QINCO_LAMBDA {
-            f32x4 w = take.template operator()<(ob * NEB + ib) * 4 + q>();
-            mfma4.template operator()<q>(y[ob], w, z[ib]);
+            fragmm.template operator()<(ob * NEB + ib) * 4 + q, q>(y[ob], z[ib], noop);
           });
         });
       });
@@ -326,8 +406,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
         acc[ob & 1] = zero16();
         static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
           static_for<4>([&]<int q>() QINCO_LAMBDA {
-            f32x4 w = take.template operator()<(ob * NHB + ib) * 4 + q>();
-            mfma4.template operator()<q>(acc[ob & 1], w, y[ib]);
+            fragmm.template operator()<(ob * NHB + ib) * 4 + q, q>(acc[ob & 1], y[ib], noop);
             if constexpr (q == 0 && ob == 0 && ib + 1 < NHB) relu16(y[ib + 1]);
             if constexpr (q == 0 && ib == 0 && ob > 0) z[ob - 1] = z[ob - 1] + acc[(ob - 1) & 1];
           });
@@ -353,12 +432,15 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     f32x16 o;
     if constexpr (PROJ) {
       o = zero16();
+      [[maybe_unused]] f32x16 o1 = zero16();
       static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
         static_for<4>([&]<int q>() QINCO_LAMBDA {
-          f32x4 w = take.template operator()<(ob * NEB + ib) * 4 + q>();
-          mfma4.template operator()<q>(o, w, z[ib]);
+          constexpr int TI = (ob * NEB + ib) * 4 + q;
+          if constexpr (DUAL && (TI & 1)) fragmm.template operator()<TI, q>(o1, z[ib], noop);
+          else fragmm.template operator()<TI, q>(o, z[ib], noop);
         });
       });
+      if constexpr (DUAL) o = o + o1;
     } else {
       o = z[ob];
     }

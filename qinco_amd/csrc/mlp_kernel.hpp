@@ -7,17 +7,23 @@
 // = QINCoStep.forward qinco/model/qinco_base.py:262-280, QConcat :60-64, QBlockFFN :93-97)
 // plus the candidate / distance epilogue of QINCoInferenceStepEncoder.forward (:190-199).
 //
-// MI355X design (not a translation of the reference's ATen op sequence):
+// MI355X design (not a translation of the reference's ATen op sequence; measurements in DESIGN.md 3.1):
 //  * The GEMMs are evaluated TRANSPOSED: Out^T[feat x rows] = W[feat_out x feat_in] . In^T[feat_in x rows]
 //    on v_mfma_f32_32x32x2_f32 (exact fp32, fmaf-chain numerics).  A wave owns 32 rows and ALL features.
 //    In the 32x32 C/D layout lane l holds row (l&31) and features {(r&3)+8(r>>2)+4(l>>5)}; that is
 //    exactly a legal B-operand layout for the next layer once the K-order of the weights is permuted
-//    the same way (host packs the weights).  Activations therefore never leave the register file:
-//    no LDS round trip, no barriers, no HBM traffic between the 2L+3 GEMMs.
+//    the same way (the host packs the weights).  Activations therefore never leave the register file:
+//    no LDS round trip and no HBM traffic between the 2L+3 GEMMs.
 //  * Weights are a single sequential stream of 1 KiB "fragments" (64 lanes x float4 = the A operands
-//    of 4 consecutive MFMAs) packed on the host in exactly the order the kernel consumes them; a P-deep
-//    register ring prefetches them from L2 / Infinity Cache (20 MB per step for qinco2-L: cache resident).
-//  * 1 wave per SIMD (z: De/2 + h: Dh/2 accumulator registers), 4 independent waves per workgroup.
+//    of 4 consecutive MFMAs) packed on the host in exactly the order the kernel consumes them, fetched through
+//    an LDS-DMA ring (global_load_lds_dwordx4) that the 4 waves of a workgroup share.
+//  * 1 wave per SIMD: z (De/2 VGPRs) + y/h (Dh/2 AGPRs) + two chain accumulators; chain epilogues (ReLU,
+//    residual add) run one chain late, under MFMAs that do not depend on them.
+//
+// Template: D, De, Dh model geometry; P ring depth in fragments; VAR feature bits (shapes.def):
+//    4 LDSR   weight stream through an LDS-DMA ring (else: P-deep register ring of plain global loads)
+//    8 PINNED explicit VGPR/AGPR plan + one-chain-late epilogues (else: eager epilogues, compiler-placed registers)
+//   64 SHR    one ring per workgroup, wave w DMAs the fragments = w (mod 4), raw s_barrier every 4 fragments
 #pragma once
 #include <hip/hip_runtime.h>
 #include <utility>
@@ -68,46 +74,28 @@ QINCO_INL float relu1(float v) {
   b = b > 0 ? b : 0;
   return __builtin_bit_cast(float, b);
 }
-// Register-class pins: empty asm statements that force a 16-register block into VGPRs / AGPRs at that point
-// (clang cannot reference lambda captures from an asm operand, hence the helpers).
-QINCO_INL void pin_v(f32x16& v) { asm volatile("" : "+v"(v)); }
-QINCO_INL void pin_a(f32x16& v) { asm volatile("" : "+a"(v)); }
-
 QINCO_INL void relu16(f32x16& v) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = relu1(v[i]);
 }
 
-// VAR bit 0 (LAZY): chain epilogues are taken off the MFMA critical path.
-//   * up-projection chains accumulate straight into y[ob]; the ReLU of block ib is applied later, inside the
-//     first down-projection chain, one block ahead of its first use (its input is long finished: no drain);
-//   * the residual add z[ob] += acc of chain ob is issued after the first input block of chain ob+1 (two
-//     alternating accumulators); only the last chain of a layer is added eagerly.
-//   Without LAZY every chain end drains the matrix pipe and runs ~64 dependent VALU ops before the next MFMA.
+// Register-class pins: empty asm statements that force a 16-register block into VGPRs / AGPRs at that point
+// (clang cannot reference lambda captures from an asm operand, hence the helpers).
+QINCO_INL void pin_v(f32x16& v) { asm volatile("" : "+v"(v)); }
+QINCO_INL void pin_a(f32x16& v) { asm volatile("" : "+a"(v)); }
+
 template <int D, int DE, int DH, int P, int VAR>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   constexpr StreamDims SL = stream_dims(D, DE, DH, P);
   constexpr int NDB = SL.NDB, NEB = SL.NEB, NHB = SL.NHB;
   constexpr bool PROJ = SL.PROJ;
   constexpr int NYB = NHB > NEB ? NHB : NEB;
-  constexpr bool LAZY = (VAR & 1) != 0;
   constexpr bool LDSR = (VAR & 4) != 0;
   constexpr bool PINNED = (VAR & 8) != 0;
-  constexpr bool FINE = (VAR & 16) != 0;  // hand-placed interleave of the ring traffic between the 4 MFMAs of a fragment
-  static_assert(!FINE || LDSR, "FINE needs the LDS ring");
-  // DUAL: consecutive fragments of a chain accumulate into two alternating accumulators (summed at the chain end).
-  // The 4 MFMAs of one fragment stay back-to-back on one accumulator (the matrix pipe forwards srcC), but the ring
-  // instructions that follow every fragment then sit between MFMAs on DIFFERENT accumulators: an instruction
-  // between two MFMAs on the SAME accumulator costs ~+43 cycles (MI355X_MICROARCH.md, per-instruction constants),
-  // which was ~12 % of this kernel.
-  constexpr bool DUAL = (VAR & 32) != 0;
-  static_assert(!DUAL || PINNED, "DUAL is implemented on the pinned plan");
-  // SHR: ONE LDS ring per workgroup instead of one per wave.  Issuing a global_load_lds costs the issuing wave
-  // ~20 cycles of matrix-pipe idle wherever it is placed (scripts/ubench/frag_loop.hip: 278 -> 264 cycles per
-  // fragment), and the four waves of a workgroup fetch the same bytes: so wave w DMAs only the fragments = w (mod 4)
-  // and a raw s_barrier every 4 fragments -- after the issuers' counted vmcnt -- publishes the landed group.
   constexpr bool SHR = (VAR & 64) != 0;
+  static_assert((VAR & ~(4 | 8 | 64)) == 0, "unknown VAR bits");
   static_assert(!SHR || (LDSR && P % 12 == 0 && P / 4 >= 5), "shared ring: P multiple of 12 (3 register sets, 4 issuers)");
+  static_assert(!LDSR || SHR || (P % 3 == 0 && P >= 6 && P <= 39), "per-wave LDS rings: 4 x P KiB must fit 160 KiB");
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -125,14 +113,18 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   const float* xhptr = a.xhat + g * D + half * 4;
 
   // ---- weight stream ---------------------------------------------------------------------------------
-  // Two implementations of take<T>() = "fragment T of the current section" (sections start at multiples of P):
-  //  * register ring (VAR bit 2 clear): P fragments prefetched into VGPRs by plain global loads;
-  //  * LDS-DMA ring (VAR bit 2 set, LDSR): each wave owns P KiB of LDS (P = 32: 128 KiB per workgroup) that
-  //    global_load_lds_dwordx4 fills P-1 fragments (~8k cycles) ahead with no VGPR cost; a 2-deep register
-  //    pair is read from LDS one fragment ahead (ds_read_b128, lane-linear = conflict free).  Waves never touch
-  //    each other's ring, so there is no barrier; ordering is the issuing wave's own counted vmcnt / lgkmcnt.
-  //    The deep ring hides Infinity-Cache latency of the lock-stepped stream (9.7 % of wave time was parked in
-  //    s_waitcnt with the 8-deep register ring, profiles/r01_*).
+  // take<T>() = "fragment T of the current section" (sections are padded to multiples of P).
+  //  * register ring (!LDSR): P fragments prefetched into VGPRs by plain global loads (round-1 first kernel: 9.7 % of
+  //    wave time parked in s_waitcnt -- every L2 miss of the lock-stepped stream stalls all CUs of an XCD);
+  //  * LDS-DMA ring (LDSR): global_load_lds_dwordx4 fills LDS far ahead at no VGPR cost, a 3-set register ring is read
+  //    from LDS two fragments ahead (ds_read_b128, lane-linear = conflict free).  hipcc does NOT order a ds_read
+  //    behind an in-flight LDS-DMA, so that side is a counted vmcnt by hand; the LDS reads are ordinary loads, so
+  //    hipcc counts lgkmcnt and no register is ever "in flight" behind its back.
+  //      - per-wave rings (!SHR): no barriers, but every wave issues one DMA per fragment;
+  //      - shared ring (SHR): issuing a global_load_lds costs the issuing wave ~20 cycles of matrix-pipe idle wherever
+  //        it is placed (scripts/ubench/frag_loop.hip: 278 -> 264 cycles per fragment) and the four waves fetch the
+  //        same bytes: wave w DMAs only the fragments = w (mod 4) and a raw s_barrier every 4 fragments -- after the
+  //        issuers' counted vmcnt -- publishes the landed group.
   const f32x4* wp = a.wstream + lane;
   constexpr int NRING = LDSR ? 3 : P;
   f32x4 ring[NRING];
@@ -147,8 +139,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
                                      (__attribute__((address_space(3))) void*)(myring + wofs + (T % P) * 64), 16, 0, 0);
   };
   // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields = "no wait"): the builtin keeps the wait visible to hipcc's
-  // own counter bookkeeping (an asm s_waitcnt made it fall back to lgkmcnt(0) everywhere); the empty asm fences
-  // pin the LDS reads / DMAs of the ring on their side of the wait.
+  // own counter bookkeeping; the empty asm fences pin the LDS reads / DMAs of the ring on their side of the wait.
   auto wait_vm = [&]<int N>() QINCO_LAMBDA {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
@@ -162,7 +153,6 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     ring[0] = myring[lane];
     ring[1] = myring[64 + lane];
   } else if constexpr (LDSR) {
-    static_assert(P % 3 == 0 && P >= 6 && P <= 39, "LDS ring depth (3 register sets: P must be a multiple of 3)");
     static_for<P - 1>([&]<int i>() QINCO_LAMBDA { dma.template operator()<i>(); });
     wait_vm.template operator()<P - 2>();  // fragment 0 has landed
     ring[0] = myring[lane];
@@ -173,28 +163,22 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
   }
   auto take = [&]<int T>() QINCO_LAMBDA -> f32x4 {
-    if constexpr (LDSR) {
-      // ring[T&1] holds fragment T (LDS read issued one step ago; hipcc counts lgkmcnt for it and keeps its
-      // registers safe).  hipcc does NOT order a ds_read behind an in-flight LDS-DMA, so the DMA side is ours:
-      // fragment T+1's DMA is P-3 DMAs old -> counted vmcnt (a "memory" asm is also a fence that pins the LDS
-      // read and the DMA below).  Then refill the slot of fragment T-1 with fragment T+P-1.
-      // fragments T, T+1 are in ring[] (3 register sets, read two steps ahead so that the LDS latency hides
-      // wherever the scheduler puts the read); fragment T+2's DMA is P-4 DMAs old.
-      if constexpr (SHR) {
-        // Before fragment T = 4g every wave has issued g + P/4 - 1 DMAs; "<= P/4 - 3 outstanding" = its first g + 2
-        // landed, so past the barrier fragments <= 4g + 7 are in LDS: covers the reads (<= 4g + 5) of this group.
-        // The refill below overwrites fragment T - 4 <= 4g - 1, which every wave consumed before this barrier.
-        if constexpr ((T & 3) == 0) {
-          wait_vm.template operator()<P / 4 - 3>();
-          __builtin_amdgcn_s_barrier();
-          dma.template operator()<T + P - 4>();
-        }
-        ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
-      } else {
-        wait_vm.template operator()<P - 4>();
-        ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
-        dma.template operator()<T + P - 1>();
+    if constexpr (SHR) {
+      // Before fragment T = 4g every wave has issued g + P/4 - 1 DMAs; "<= P/4 - 3 outstanding" = its first g + 2
+      // landed, so past the barrier fragments <= 4g + 7 are in LDS: covers the reads (<= 4g + 5) of this group.
+      // The refill overwrites fragments 4g - 4 .. 4g - 1, which every wave consumed before this barrier.
+      if constexpr ((T & 3) == 0) {
+        wait_vm.template operator()<P / 4 - 3>();
+        __builtin_amdgcn_s_barrier();
+        dma.template operator()<T + P - 4>();
       }
+      ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
+      return ring[T % 3];
+    } else if constexpr (LDSR) {
+      // fragments T, T+1 are in ring[]; fragment T+2's DMA is P-4 DMAs old; refill the slot of fragment T-1.
+      wait_vm.template operator()<P - 4>();
+      ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
+      dma.template operator()<T + P - 1>();
       return ring[T % 3];
     } else {
       f32x4 w = ring[T % P];
@@ -205,38 +189,13 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   auto skip_pad = [&]<int FROM, int TO>() QINCO_LAMBDA {
     static_for<TO - FROM>([&]<int i>() QINCO_LAMBDA { (void)take.template operator()<FROM + i>(); });
   };
-  // 4 MFMAs of one fragment: acc += W[ob, 8 features of block ib] . b
-  auto mfma4 = [&]<int q>(f32x16& acc, const f32x4& w, const f32x16& b) QINCO_LAMBDA {
-    static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA(w[e], b[4 * q + e], acc); });
-  };
-
-  // One fragment = 4 dependent MFMAs (256 cycles of matrix pipe).  Everything else the fragment needs -- the
-  // counted wait + LDS read of a later fragment, the DMA refill (~60 issue cycles), the chain-epilogue slice
-  // `extra` -- must sit in the three 64-cycle shadows BETWEEN those MFMAs; hipcc clumps them behind the 4th MFMA
-  // (one ~100-cycle gap = ~36 idle pipe cycles per fragment).  FINE pins the placement with sched_barrier(0).
+  // One fragment: acc += W[ob, 8 features (4q..4q+3 of each half) of block ib] . b  (4 dependent MFMAs), then `extra`
+  // (a slice of a chain epilogue that the following MFMAs do not depend on).
   auto noop = []() QINCO_LAMBDA {};
   auto fragmm = [&]<int T, int q>(f32x16& acc, const f32x16& b, auto&& extra) QINCO_LAMBDA {
-    if constexpr (FINE) {
-      const f32x4 w = ring[T % 3];
-      acc = QINCO_MFMA(w[0], b[4 * q + 0], acc);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_vm.template operator()<P - 4>();
-      ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
-      __builtin_amdgcn_sched_barrier(0);
-      acc = QINCO_MFMA(w[1], b[4 * q + 1], acc);
-      __builtin_amdgcn_sched_barrier(0);
-      dma.template operator()<T + P - 1>();
-      __builtin_amdgcn_sched_barrier(0);
-      acc = QINCO_MFMA(w[2], b[4 * q + 2], acc);
-      __builtin_amdgcn_sched_barrier(0);
-      extra();
-      __builtin_amdgcn_sched_barrier(0);
-      acc = QINCO_MFMA(w[3], b[4 * q + 3], acc);
-    } else {
-      const f32x4 w = take.template operator()<T>();
-      mfma4.template operator()<q>(acc, w, b);
-      extra();
-    }
+    const f32x4 w = take.template operator()<T>();
+    static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA(w[e], b[4 * q + e], acc); });
+    extra();
   };
 
   f32x16 z[NEB];
@@ -297,68 +256,58 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   if constexpr (PINNED) {
     // Register-file plan (the compiler is told, not asked): z lives in VGPRs (B operand of the up-projection,
     // VALU-updated by the residual add), y lives in AGPRs (B operand of the down-projection, never touched by
-    // VALU after it is written), chain accumulators are temporaries.  Epilogues run one chain late:
-    //   up:   y[ob-1] = relu(prev)  (16 v_max_i32 + 16 v_accvgpr_write) under chain ob's first MFMAs
-    //   down: z[ob-1] += prev       (16 v_add_f32, all-VGPR)            under chain ob's first MFMAs
+    // VALU after it is written), chain accumulators t[2] alternate.  Epilogues run one chain late, a quarter per
+    // fragment, under MFMAs that do not depend on them (an eager epilogue drains the matrix pipe at each of the
+    // 24 chain ends per layer: s_nop 15 + ~64 dependent VALU ops):
+    //   up:   y[ob-1] = relu(t_prev)  (16 v_max_i32 + 16 v_accvgpr_write)
+    //   down: z[ob-1] += t_prev       (16 v_add_f32)
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA { pin_v(z[ob]); });
 #pragma unroll 1
     for (int l = 0; l < a.L; ++l) {
-      f32x16 t[2];     // !DUAL: chain ob accumulates in t[ob&1], t[(ob-1)&1] is the finished previous chain
-      f32x16 prev;     //  DUAL: t[0], t[1] alternate per fragment; prev = their sum for the finished chain
+      f32x16 t[2];
       static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
-        if constexpr (DUAL) { t[0] = zero16(); t[1] = zero16(); } else { t[ob & 1] = zero16(); }
+        t[ob & 1] = zero16();
         static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
           static_for<4>([&]<int q>() QINCO_LAMBDA {
             constexpr int TI = (ob * NEB + ib) * 4 + q;
-            f32x16& acc = t[DUAL ? (TI & 1) : (ob & 1)];
-            if constexpr (ib == 0 && ob > 0) {  // a quarter of the previous chain's epilogue per fragment
-              fragmm.template operator()<TI, q>(acc, z[ib], [&]() QINCO_LAMBDA {
-                static_for<4>([&]<int e>() QINCO_LAMBDA {
-                  y[ob - 1][4 * q + e] = relu1(DUAL ? prev[4 * q + e] : t[(ob - 1) & 1][4 * q + e]);
-                });
+            if constexpr (ib == 0 && ob > 0) {
+              fragmm.template operator()<TI, q>(t[ob & 1], z[ib], [&]() QINCO_LAMBDA {
+                static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob - 1][4 * q + e] = relu1(t[(ob - 1) & 1][4 * q + e]); });
               });
               if constexpr (q == 3) pin_a(y[ob - 1]);
             } else {
-              fragmm.template operator()<TI, q>(acc, z[ib], noop);
+              fragmm.template operator()<TI, q>(t[ob & 1], z[ib], noop);
             }
           });
         });
-        if constexpr (DUAL) prev = t[0] + t[1];
       });
-      {
-        f32x16& last = DUAL ? prev : t[(NHB - 1) & 1];
-        relu16(last);
-        y[NHB - 1] = last;
-        pin_a(y[NHB - 1]);
-      }
+      relu16(t[(NHB - 1) & 1]);
+      y[NHB - 1] = t[(NHB - 1) & 1];
+      pin_a(y[NHB - 1]);
       skip_pad.template operator()<NHB * NEB * 4, SL.T_UP>();
       wp += SL.T_UP * 64;
       static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-        if constexpr (DUAL) { t[0] = zero16(); t[1] = zero16(); } else { t[ob & 1] = zero16(); }
+        t[ob & 1] = zero16();
         static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
           static_for<4>([&]<int q>() QINCO_LAMBDA {
             constexpr int TI = (ob * NHB + ib) * 4 + q;
-            f32x16& acc = t[DUAL ? (TI & 1) : (ob & 1)];
             if constexpr (ib == 0 && ob > 0) {
-              fragmm.template operator()<TI, q>(acc, y[ib], [&]() QINCO_LAMBDA {
-                static_for<4>([&]<int e>() QINCO_LAMBDA {
-                  z[ob - 1][4 * q + e] += DUAL ? prev[4 * q + e] : t[(ob - 1) & 1][4 * q + e];
-                });
+              fragmm.template operator()<TI, q>(t[ob & 1], y[ib], [&]() QINCO_LAMBDA {
+                static_for<4>([&]<int e>() QINCO_LAMBDA { z[ob - 1][4 * q + e] += t[(ob - 1) & 1][4 * q + e]; });
               });
               if constexpr (q == 3) pin_v(z[ob - 1]);
             } else {
-              fragmm.template operator()<TI, q>(acc, y[ib], noop);
+              fragmm.template operator()<TI, q>(t[ob & 1], y[ib], noop);
             }
           });
         });
-        if constexpr (DUAL) prev = t[0] + t[1];
       });
-      z[NEB - 1] = z[NEB - 1] + (DUAL ? prev : t[(NEB - 1) & 1]);
+      z[NEB - 1] = z[NEB - 1] + t[(NEB - 1) & 1];  // the only chain end per layer that drains the pipe
       pin_v(z[NEB - 1]);
       skip_pad.template operator()<NEB * NHB * 4, SL.T_DOWN>();
       wp += SL.T_DOWN * 64;
     }
-  } else if constexpr (!LAZY) {
+  } else {
 #pragma unroll 1
     for (int l = 0; l < a.L; ++l) {
       static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
@@ -385,37 +334,6 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
       skip_pad.template operator()<NEB * NHB * 4, SL.T_DOWN>();
       wp += SL.T_DOWN * 64;
     }
-  } else {
-#pragma unroll 1
-    for (int l = 0; l < a.L; ++l) {
-      // up-projection: chains accumulate in place in y[ob]; no epilogue here
-      static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
-        y[ob] = zero16();
-        static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
-          static_for<4>([&]<int q>() QINCO_LAMBDA {
-            fragmm.template operator()<(ob * NEB + ib) * 4 + q, q>(y[ob], z[ib], noop);
-          });
-        });
-      });
-      skip_pad.template operator()<NHB * NEB * 4, SL.T_UP>();
-      wp += SL.T_UP * 64;
-      // down-projection: lazy ReLU one block ahead, residual adds one chain behind
-      f32x16 acc[2];
-      relu16(y[0]);
-      static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-        acc[ob & 1] = zero16();
-        static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
-          static_for<4>([&]<int q>() QINCO_LAMBDA {
-            fragmm.template operator()<(ob * NHB + ib) * 4 + q, q>(acc[ob & 1], y[ib], noop);
-            if constexpr (q == 0 && ob == 0 && ib + 1 < NHB) relu16(y[ib + 1]);
-            if constexpr (q == 0 && ib == 0 && ob > 0) z[ob - 1] = z[ob - 1] + acc[(ob - 1) & 1];
-          });
-        });
-      });
-      z[NEB - 1] = z[NEB - 1] + acc[(NEB - 1) & 1];  // the only chain end per layer that drains the pipe
-      skip_pad.template operator()<NEB * NHB * 4, SL.T_DOWN>();
-      wp += SL.T_DOWN * 64;
-    }
   }
 
   // ---- E: out_proj + epilogue: cand = (out + coeff*c) + xhat ; dist = |x|^2 + |cand|^2 - 2 x.cand
@@ -432,15 +350,11 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     f32x16 o;
     if constexpr (PROJ) {
       o = zero16();
-      [[maybe_unused]] f32x16 o1 = zero16();
       static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
         static_for<4>([&]<int q>() QINCO_LAMBDA {
-          constexpr int TI = (ob * NEB + ib) * 4 + q;
-          if constexpr (DUAL && (TI & 1)) fragmm.template operator()<TI, q>(o1, z[ib], noop);
-          else fragmm.template operator()<TI, q>(o, z[ib], noop);
+          fragmm.template operator()<(ob * NEB + ib) * 4 + q, q>(o, z[ib], noop);
         });
       });
-      if constexpr (DUAL) o = o + o1;
     } else {
       o = z[ob];
     }

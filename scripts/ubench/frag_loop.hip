@@ -39,7 +39,9 @@ __global__ void __launch_bounds__(256) k(const f32x4* __restrict__ w, float* out
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds + slot * 64), 16, 0, 0);
   };
-  if (MODE == 13 || MODE == 14) {
+  if (MODE == 15) {
+    for (int i = 0; i < P - 8; ++i) if ((i & 3) == wave) dma_sh(i, wp + i * 64);
+  } else if (MODE == 13 || MODE == 14 || MODE == 16 || MODE == 17) {
     for (int i = 0; i < P - 4; ++i) if ((i & 3) == wave) dma_sh(i, wp + i * 64);
   } else if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7 || MODE >= 8)
     for (int i = 0; i < P - 1; ++i) dma(i, wp + i * 64);
@@ -112,6 +114,37 @@ __global__ void __launch_bounds__(256) k(const f32x4* __restrict__ w, float* out
         } else {
           acc0 = MF(x[0], b, acc0); acc0 = MF(x[1], b, acc0); acc0 = MF(x[2], b, acc0); acc0 = MF(x[3], b, acc0);
         }
+      } else if constexpr (MODE == 15) {
+        // shared ring, barrier every 8 fragments, each wave DMAs 2 of the 8
+        f32x4* shring = lds;
+        if ((t & 7) == 0) {
+          waitvm<(P / 4) - 4>();
+          __builtin_amdgcn_s_barrier();
+          dma_sh((t + P - 8) % P + wave, wp + (t + P - 8 + wave) * 64);
+          dma_sh((t + P - 4) % P + wave, wp + (t + P - 4 + wave) * 64);
+        }
+        r[(t + 2) & 7] = shring[((t + 2) % P) * 64 + lane];
+        acc0 = MF(x[0], b, acc0); acc0 = MF(x[1], b, acc0); acc0 = MF(x[2], b, acc0); acc0 = MF(x[3], b, acc0);
+      } else if constexpr (MODE == 16) {
+        // shared ring as MODE 13 but branch-free issue (wave offset folded into the pointers), like the real kernel
+        f32x4* shring = lds;
+        if ((t & 3) == 0) {
+          waitvm<(P / 4) - 3>();
+          __builtin_amdgcn_s_barrier();
+          dma_sh((t + P - 4) % P + wave, wp + (t + P - 4 + wave) * 64);
+        }
+        r[(t + 2) & 7] = shring[((t + 2) % P) * 64 + lane];
+        acc0 = MF(x[0], b, acc0); acc0 = MF(x[1], b, acc0); acc0 = MF(x[2], b, acc0); acc0 = MF(x[3], b, acc0);
+      } else if constexpr (MODE == 17) {
+        // MODE 16 with a 2-deep register ring read ONE fragment ahead
+        f32x4* shring = lds;
+        if ((t & 3) == 0) {
+          waitvm<(P / 4) - 3>();
+          __builtin_amdgcn_s_barrier();
+          dma_sh((t + P - 4) % P + wave, wp + (t + P - 4 + wave) * 64);
+        }
+        r[(t + 1) & 7] = shring[((t + 1) % P) * 64 + lane];
+        acc0 = MF(x[0], b, acc0); acc0 = MF(x[1], b, acc0); acc0 = MF(x[2], b, acc0); acc0 = MF(x[3], b, acc0);
       } else if constexpr (MODE == 5) {
         acc0 = MF(x[0], b, acc0); acc0 = MF(x[1], b, acc0); acc0 = MF(x[2], b, acc0); acc0 = MF(x[3], b, acc0);
         r[t & 7] = wp[(t + 8) * 64];
@@ -144,6 +177,6 @@ int main() {
   const int iters = 544;   // 544 x 36 = 19584 fragments = one C2 step's stream (20 MB)
   f32x4* w; hipMalloc(&w, (size_t)(iters + 2) * P * 1024); hipMemset(w, 0, (size_t)(iters + 2) * P * 1024);
   run<0>(w, iters); run<1>(w, iters); run<2>(w, iters); run<3>(w, iters); run<4>(w, iters); run<5>(w, iters);
-  run<6>(w, iters); run<7>(w, iters); run<8>(w, iters); run<9>(w, iters); run<10>(w, iters); run<11>(w, iters); run<12>(w, iters); run<13>(w, iters); run<14>(w, iters);
+  run<6>(w, iters); run<7>(w, iters); run<8>(w, iters); run<9>(w, iters); run<10>(w, iters); run<11>(w, iters); run<12>(w, iters); run<13>(w, iters); run<14>(w, iters); run<15>(w, iters); run<16>(w, iters); run<17>(w, iters);
   return 0;
 }

@@ -253,3 +253,35 @@ def test_ivf_full_scale_assignment():
         bad_codes[0, 0] = cfg.ivf_K
         eng.decode(bad_codes)
     eng.close()
+
+
+def _production_shapes():
+    import re
+    from conftest import ROOT
+    seen, out = set(), []
+    for m in re.finditer(r"^QINCO_SHAPE\((\d+),\s*(\d+),\s*(\d+),", (ROOT / "qinco_amd/csrc/shapes.def").read_text(), re.M):
+        s = tuple(int(v) for v in m.groups())
+        if s not in seen:
+            seen.add(s)
+            out.append(s)
+    return out
+
+
+@pytest.mark.parametrize("shape", _production_shapes(), ids=lambda s: "x".join(map(str, s)))
+def test_every_kernel_instance_matches_oracle(shape):
+    """Each (D, De, Dh) instance in shapes.def, on a short model with beam search, against the oracle."""
+    from qinco_amd import QincoConfig, QincoEngine, synth_state_dict, synth_vectors
+    D, De, Dh = shape
+    cfg = QincoConfig(D=D, M=3, K=256, L=2, de=(None if De == D else De), dh=Dh, A=8, B=4, qinco1_mode=(De == D))
+    sd = synth_state_dict(cfg, 4321 + D + De)
+    x = synth_vectors(cfg, sd, 130, seed=17)
+    eng = QincoEngine(cfg, sd, max_batch=128)
+    got = eng.encode(x)
+    oracle = make_oracle(cfg, sd)
+    want = oracle(x, step="encode").T
+    bad = int((got != want).any(axis=1).sum())
+    assert bad <= 2, f"{bad} of {len(x)} rows differ"
+    dec = eng.decode(want)
+    ref = oracle(want.T, step="decode")
+    assert np.abs(dec - ref).max() / np.abs(ref).max() < REL_TOL
+    eng.close()

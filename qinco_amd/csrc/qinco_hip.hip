@@ -605,6 +605,7 @@ extern "C" int qinco_encode(qinco_handle h, const void* x, int x_dtype, int64_t 
                             int code_dtype, float* xhat_out, int flags, void* stream) {
   int rc = check_common(h, x, codes_out, n, code_dtype, "qinco_encode");
   if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->device));  // a handle is bound to the device it was created on
   if (x_dtype != QINCO_X_F32 && x_dtype != QINCO_X_U8) return fail(QINCO_ERR_INVALID, "qinco_encode: bad x dtype %d", x_dtype);
   const size_t esz = x_dtype == QINCO_X_F32 ? 4 : 1;
   if (stride == 0) stride = (int64_t)(h->d.D * esz);
@@ -660,6 +661,7 @@ extern "C" int qinco_decode(qinco_handle h, const void* codes, int code_dtype, i
                             void* stream) {
   int rc = check_common(h, codes, out, n, code_dtype, "qinco_decode");
   if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->device));
   if ((rc = ensure_decode_scratch(h, n))) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   for (int64_t i0 = 0; i0 < n; i0 += h->dec_cap) {
@@ -689,20 +691,31 @@ extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int
   if (rc) return rc;
   if (x_dtype != QINCO_X_F32 && x_dtype != QINCO_X_U8) return fail(QINCO_ERR_INVALID, "qinco_encode_host: bad x dtype");
   if (n == 0) return QINCO_OK;
+  HIP_TRY(hipSetDevice(h->device));
   const size_t esz = x_dtype == QINCO_X_F32 ? 4 : 1;
   const size_t rowb = (size_t)h->d.D * esz;
   if (stride == 0) stride = (int64_t)rowb;
   if (stride < (int64_t)rowb) return fail(QINCO_ERR_INVALID, "qinco_encode_host: row stride smaller than a row");
-  const size_t cb = (size_t)n * h->d.M * code_size(code_dtype);
-  if ((rc = ensure_stage(&h->stage_x, &h->stage_x_bytes, (size_t)n * rowb))) return rc;
-  if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, cb))) return rc;
-  if (xhat_out && (rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, (size_t)n * h->d.D * 4))) return rc;
-  HIP_TRY(hipMemcpy2D(h->stage_x, rowb, x, (size_t)stride, rowb, (size_t)n, hipMemcpyHostToDevice));
-  if ((rc = qinco_encode(h, h->stage_x, x_dtype, 0, n, h->stage_codes, code_dtype, xhat_out ? h->stage_out : nullptr, flags,
-                         nullptr)))
-    return rc;
-  HIP_TRY(hipMemcpy(codes_out, h->stage_codes, cb, hipMemcpyDeviceToHost));
-  if (xhat_out) HIP_TRY(hipMemcpy(xhat_out, h->stage_out, (size_t)n * h->d.D * 4, hipMemcpyDeviceToHost));
+  // staged in passes of max_batch rows, so a whole database (search_tasks.py:107-116 feeds 1e9 rows) never has to
+  // fit the device twice
+  const int64_t pass = h->d.max_batch;
+  const size_t crow = (size_t)h->d.M * code_size(code_dtype);
+  const int64_t cap = n < pass ? n : pass;
+  if ((rc = ensure_stage(&h->stage_x, &h->stage_x_bytes, (size_t)cap * rowb))) return rc;
+  if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, (size_t)cap * crow))) return rc;
+  if (xhat_out && (rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, (size_t)cap * h->d.D * 4))) return rc;
+  for (int64_t i0 = 0; i0 < n; i0 += pass) {
+    const int64_t nb = n - i0 < pass ? n - i0 : pass;
+    const char* xp = reinterpret_cast<const char*>(x) + i0 * stride;
+    HIP_TRY(hipMemcpy2D(h->stage_x, rowb, xp, (size_t)stride, rowb, (size_t)nb, hipMemcpyHostToDevice));
+    if ((rc = qinco_encode(h, h->stage_x, x_dtype, 0, nb, h->stage_codes, code_dtype, xhat_out ? h->stage_out : nullptr, flags,
+                           nullptr)))
+      return rc;
+    HIP_TRY(hipMemcpy(reinterpret_cast<char*>(codes_out) + (size_t)i0 * crow, h->stage_codes, (size_t)nb * crow,
+                      hipMemcpyDeviceToHost));
+    if (xhat_out)
+      HIP_TRY(hipMemcpy(xhat_out + (size_t)i0 * h->d.D, h->stage_out, (size_t)nb * h->d.D * 4, hipMemcpyDeviceToHost));
+  }
   return QINCO_OK;
 }
 
@@ -720,13 +733,20 @@ extern "C" int qinco_decode_host(qinco_handle h, const void* codes, int code_dty
   int rc = check_common(h, codes, out, n, code_dtype, "qinco_decode_host");
   if (rc) return rc;
   if (n == 0) return QINCO_OK;
-  const size_t cb = (size_t)n * h->d.M * code_size(code_dtype);
-  const size_t ob = (size_t)n * h->d.D * 4;
-  if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, cb))) return rc;
-  if ((rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, ob))) return rc;
-  HIP_TRY(hipMemcpy(h->stage_codes, codes, cb, hipMemcpyHostToDevice));
-  if ((rc = qinco_decode(h, h->stage_codes, code_dtype, n, h->stage_out, flags, nullptr))) return rc;
-  HIP_TRY(hipMemcpy(out, h->stage_out, ob, hipMemcpyDeviceToHost));
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t crow = (size_t)h->d.M * code_size(code_dtype);
+  const size_t orow = (size_t)h->d.D * 4;
+  const int64_t pass = kDecodeChunk;
+  const int64_t cap = n < pass ? n : pass;
+  if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, (size_t)cap * crow))) return rc;
+  if ((rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, (size_t)cap * orow))) return rc;
+  for (int64_t i0 = 0; i0 < n; i0 += pass) {
+    const int64_t nb = n - i0 < pass ? n - i0 : pass;
+    HIP_TRY(hipMemcpy(h->stage_codes, reinterpret_cast<const char*>(codes) + (size_t)i0 * crow, (size_t)nb * crow,
+                      hipMemcpyHostToDevice));
+    if ((rc = qinco_decode(h, h->stage_codes, code_dtype, nb, h->stage_out, flags, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(out + (size_t)i0 * h->d.D, h->stage_out, (size_t)nb * orow, hipMemcpyDeviceToHost));
+  }
   return check_decode_range(h);
 }
 

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--beams", type=int, nargs="*", default=None, help="override B (e.g. 1 8)")
+    ap.add_argument("--host", action="store_true", help="also time the host-buffer entry points (PCIe inclusive)")
     args = ap.parse_args()
     import torch
     from qinco_amd import QincoEngine, synth_codes, synth_state_dict, synth_vectors
@@ -59,6 +60,16 @@ def main():
                                   "gflop_per_vector": eng.flops_per_vector(mode) / 1e9,
                                   "mlp_tflops": tf, "mlp_frac_of_fp32_mfma_peak": tf / PEAK,
                                   "mlp_share_of_time": pr["mlp_ms"] * 1e-3 / dt}), flush=True)
+        if args.host:   # numpy in / numpy out through qinco_encode_host: H2D of x and D2H of the codes are inside the time
+            eng.set_beam(B=beams[-1])
+            xh = x.cpu().numpy()
+            eng.encode(xh)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.encode(xh)
+            dt = time.perf_counter() - t0
+            print(json.dumps({"workload": wl, "mode": "encode_host(PCIe inclusive)", "B": beams[-1],
+                              "vectors_per_s": args.steps * args.batch / dt}), flush=True)
         eng.close()
 
 

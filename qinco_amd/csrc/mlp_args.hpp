@@ -18,15 +18,17 @@ struct StreamDims {
   constexpr long total(int L) const { return (long)T_IN + T_BIAS + T_CAT + (long)L * (T_UP + T_DOWN) + T_OUT; }
 };
 
-constexpr StreamDims stream_dims(int D, int DE, int DH, int P) {
+// fold = true: in_proj / bias / concat are not in the stream (the kernel starts from z = T[cid] + U[group], see
+// mlp_kernel.hpp FOLD).
+constexpr StreamDims stream_dims(int D, int DE, int DH, int P, bool fold = false) {
   StreamDims s{};
   s.NDB = D / 32;
   s.NEB = DE / 32;
   s.NHB = DH / 32;
   s.PROJ = (D != DE);
-  s.T_IN = s.PROJ ? round_up(s.NEB * s.NDB * 4, P) : 0;
-  s.T_BIAS = round_up(s.NEB * 4, P);
-  s.T_CAT = round_up(s.NEB * (s.NEB + s.NDB) * 4, P);
+  s.T_IN = (s.PROJ && !fold) ? round_up(s.NEB * s.NDB * 4, P) : 0;
+  s.T_BIAS = fold ? 0 : round_up(s.NEB * 4, P);
+  s.T_CAT = fold ? 0 : round_up(s.NEB * (s.NEB + s.NDB) * 4, P);
   s.T_UP = round_up(s.NHB * s.NEB * 4, P);
   s.T_DOWN = round_up(s.NEB * s.NHB * 4, P);
   s.T_OUT = s.PROJ ? round_up(s.NDB * s.NEB * 4, P) : 0;
@@ -46,6 +48,15 @@ struct MlpArgs {
   float* cand_out;        // (R, D): f(c,xhat)+xhat
   float* dist_out;        // (R) or nullptr
   int add_c;              // 1: + c (QINCo2), 0: qinco1_mode (res_codeword_coeff = 0)
+  const float* ttab;      // FOLD: (K, De) per-codeword table  T_k = z_k + W_cat[:, :De] z_k + b,  z_k = in_proj(c_k)
+  const float* uproj;     // FOLD: (R/A, De) per-group  U_g = W_cat[:, De:] xhat_g   (xproj_kernel)
+};
+
+struct XprojArgs {
+  const f32x4* wx;        // W_cat[:, De:] (De x D) as fragments in (ob, ib, q) order
+  const float* xhat;      // (G, D)
+  float* uproj;           // (G, De)
+  long G;
 };
 
 }  // namespace qinco

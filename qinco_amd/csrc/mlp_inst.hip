@@ -13,3 +13,11 @@ hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::Mlp
   hipLaunchKernelGGL((qinco::mlp_kernel<QD, QDE, QDH, QP, QVAR>), dim3(grid), dim3(256), 0, stream, *a);
   return hipGetLastError();
 }
+
+extern "C" __attribute__((visibility("hidden")))
+hipError_t QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::XprojArgs* a, hipStream_t stream) {
+  if (a->G <= 0) return hipSuccess;
+  const unsigned grid = (unsigned)((a->G + 127) / 128);
+  hipLaunchKernelGGL((qinco::xproj_kernel<QD, QDE>), dim3(grid), dim3(256), 0, stream, *a);
+  return hipGetLastError();
+}

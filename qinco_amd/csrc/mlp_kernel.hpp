@@ -24,6 +24,11 @@
 //    4 LDSR   weight stream through an LDS-DMA ring (else: P-deep register ring of plain global loads)
 //    8 PINNED explicit VGPR/AGPR plan + one-chain-late epilogues (else: eager epilogues, compiler-placed registers)
 //   64 SHR    one ring per workgroup, wave w DMAs the fragments = w (mod 4), raw s_barrier every 4 fragments
+//   16 FOLD   the part of the MLP head that does not depend on the row is not recomputed per row:
+//             z_k = in_proj(c_k) and W_cat[:, :De] z_k + b depend only on the codeword k (a (K, De) table T built at
+//             qinco_create), W_cat[:, De:] xhat depends only on the (vector, beam) group (U, one small MFMA GEMM per
+//             step: xproj_kernel).  The kernel starts from z = T[cid] + U[group]: -4.9 % MFMA work at C2.
+//             Same real-number result as QConcat.forward; the fp32 association differs ((b + Wz z) + Wx xhat).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <utility>
@@ -86,14 +91,15 @@ QINCO_INL void pin_a(f32x16& v) { asm volatile("" : "+a"(v)); }
 
 template <int D, int DE, int DH, int P, int VAR>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
-  constexpr StreamDims SL = stream_dims(D, DE, DH, P);
+  constexpr bool FOLD = (VAR & 16) != 0;
+  constexpr StreamDims SL = stream_dims(D, DE, DH, P, FOLD);
   constexpr int NDB = SL.NDB, NEB = SL.NEB, NHB = SL.NHB;
   constexpr bool PROJ = SL.PROJ;
   constexpr int NYB = NHB > NEB ? NHB : NEB;
   constexpr bool LDSR = (VAR & 4) != 0;
   constexpr bool PINNED = (VAR & 8) != 0;
   constexpr bool SHR = (VAR & 64) != 0;
-  static_assert((VAR & ~(4 | 8 | 64)) == 0, "unknown VAR bits");
+  static_assert((VAR & ~(4 | 8 | 16 | 64)) == 0, "unknown VAR bits");
   static_assert(!SHR || (LDSR && P % 12 == 0 && P / 4 >= 5), "shared ring: P multiple of 12 (3 register sets, 4 issuers)");
   static_assert(!LDSR || SHR || (P % 3 == 0 && P >= 6 && P <= 39), "per-wave LDS rings: 4 x P KiB must fit 160 KiB");
 
@@ -201,56 +207,63 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   f32x16 z[NEB];
   f32x16 y[NYB];
 
-  // ---- A: z = in_proj(c)  (K-outer; c blocks streamed from the codebook, next block prefetched) ---------
-  if constexpr (PROJ) {
-    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = zero16(); });
-    f32x16 cb = load_block(cptr);
-    static_for<NDB>([&]<int ib>() QINCO_LAMBDA {
-      f32x16 cur = cb;
-      if constexpr (ib + 1 < NDB) cb = load_block(cptr + (ib + 1) * 32);
-      static_for<4>([&]<int q>() QINCO_LAMBDA {
-        static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-          fragmm.template operator()<(ib * 4 + q) * NEB + ob, q>(z[ob], cur, noop);
-        });
-      });
-    });
-    skip_pad.template operator()<NEB * NDB * 4, SL.T_IN>();
-    wp += SL.T_IN * 64;
+  if constexpr (FOLD) {
+    // ---- A-C folded: z = T[cid] + U[group] -----------------------------------------------------------
+    const float* tptr = a.ttab + (long)cid * DE + half * 4;
+    const float* uptr = a.uproj + g * DE + half * 4;
+    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = load_block(tptr + ob * 32) + load_block(uptr + ob * 32); });
   } else {
-    static_for<NEB>([&]<int ib>() QINCO_LAMBDA { z[ib] = load_block(cptr + ib * 32); });
-  }
-
-  // ---- B: y = bias of the concat Linear ------------------------------------------------------
-  static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-    static_for<4>([&]<int q>() QINCO_LAMBDA {
-      f32x4 w = take.template operator()<ob * 4 + q>();
-      static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob][4 * q + e] = w[e]; });
-    });
-  });
-  skip_pad.template operator()<NEB * 4, SL.T_BIAS>();
-  wp += SL.T_BIAS * 64;
-
-  // ---- C: y += W_cat . [z ; xhat]   then z = z + y   (QConcat.forward) -------------------------
-  {
-    f32x16 xb = load_block(xhptr);
-    static_for<NEB + NDB>([&]<int ib>() QINCO_LAMBDA {
-      f32x16 b;
-      if constexpr (ib < NEB) {
-        b = z[ib];
-      } else {
-        b = xb;
-        if constexpr (ib + 1 < NEB + NDB) xb = load_block(xhptr + (ib + 1 - NEB) * 32);
-      }
-      static_for<4>([&]<int q>() QINCO_LAMBDA {
-        static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-          fragmm.template operator()<(ib * 4 + q) * NEB + ob, q>(y[ob], b, noop);
+    // ---- A: z = in_proj(c)  (K-outer; c blocks streamed from the codebook, next block prefetched) ---------
+    if constexpr (PROJ) {
+      static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = zero16(); });
+      f32x16 cb = load_block(cptr);
+      static_for<NDB>([&]<int ib>() QINCO_LAMBDA {
+        f32x16 cur = cb;
+        if constexpr (ib + 1 < NDB) cb = load_block(cptr + (ib + 1) * 32);
+        static_for<4>([&]<int q>() QINCO_LAMBDA {
+          static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+            fragmm.template operator()<(ib * 4 + q) * NEB + ob, q>(z[ob], cur, noop);
+          });
         });
       });
+      skip_pad.template operator()<NEB * NDB * 4, SL.T_IN>();
+      wp += SL.T_IN * 64;
+    } else {
+      static_for<NEB>([&]<int ib>() QINCO_LAMBDA { z[ib] = load_block(cptr + ib * 32); });
+    }
+
+    // ---- B: y = bias of the concat Linear ------------------------------------------------------
+    static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+      static_for<4>([&]<int q>() QINCO_LAMBDA {
+        f32x4 w = take.template operator()<ob * 4 + q>();
+        static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob][4 * q + e] = w[e]; });
+      });
     });
+    skip_pad.template operator()<NEB * 4, SL.T_BIAS>();
+    wp += SL.T_BIAS * 64;
+
+    // ---- C: y += W_cat . [z ; xhat]   then z = z + y   (QConcat.forward) -------------------------
+    {
+      f32x16 xb = load_block(xhptr);
+      static_for<NEB + NDB>([&]<int ib>() QINCO_LAMBDA {
+        f32x16 b;
+        if constexpr (ib < NEB) {
+          b = z[ib];
+        } else {
+          b = xb;
+          if constexpr (ib + 1 < NEB + NDB) xb = load_block(xhptr + (ib + 1 - NEB) * 32);
+        }
+        static_for<4>([&]<int q>() QINCO_LAMBDA {
+          static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+            fragmm.template operator()<(ib * 4 + q) * NEB + ob, q>(y[ob], b, noop);
+          });
+        });
+      });
+    }
+    skip_pad.template operator()<NEB*(NEB + NDB) * 4, SL.T_CAT>();
+    wp += SL.T_CAT * 64;
+    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = z[ob] + y[ob]; });
   }
-  skip_pad.template operator()<NEB*(NEB + NDB) * 4, SL.T_CAT>();
-  wp += SL.T_CAT * 64;
-  static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = z[ob] + y[ob]; });
 
   // ---- D: L residual FFN blocks: z = z + W_down . relu(W_up . z)   (QBlockFFN.forward) ---------
   if constexpr (PINNED) {
@@ -384,6 +397,45 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   }
   // no LDS-DMA may be in flight when the wave ends (its LDS could be handed to the next workgroup)
   if constexpr (LDSR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// U[g] = W_cat[:, De:] . xhat_g for every (vector, beam) group (FOLD).  Same transposed-MFMA form: a wave keeps its 32
+// groups' xhat as B operands and streams the (De x D) weight fragments (L2 resident) as A operands.
+template <int D, int DE>
+__global__ void __launch_bounds__(256) xproj_kernel(XprojArgs a) {
+  constexpr int NDB = D / 32, NEB = DE / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, half = lane >> 5;
+  const long g0 = ((long)blockIdx.x * 4 + wave) * 32;
+  if (g0 >= a.G) return;
+  long g = g0 + j;
+  const bool valid = g < a.G;
+  if (!valid) g = a.G - 1;
+  const float* xp = a.xhat + g * D + half * 4;
+  f32x16 xt[NDB];
+#pragma unroll
+  for (int ib = 0; ib < NDB; ++ib) xt[ib] = load_block(xp + ib * 32);
+  const f32x4* wp = a.wx + lane;
+  float* up = a.uproj + g * DE + half * 4;
+#pragma unroll
+  for (int ob = 0; ob < NEB; ++ob) {
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int ib = 0; ib < NDB; ++ib)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 w = wp[((ob * NDB + ib) * 4 + q) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = QINCO_MFMA(w[e], xt[ib][4 * q + e], acc);
+      }
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 t = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(up + ob * 32 + 8 * q) = t;
+      }
+    }
+  }
 }
 
 }  // namespace qinco

@@ -4,10 +4,13 @@
 
 namespace qinco {
 struct MlpArgs;
+struct XprojArgs;
 typedef hipError_t (*mlp_launch_fn)(const MlpArgs*, hipStream_t);
+typedef hipError_t (*xproj_launch_fn)(const XprojArgs*, hipStream_t);
 struct MlpInstance {
   int D, De, Dh, P, var;
   mlp_launch_fn fn;
+  xproj_launch_fn xproj;   // used when var has the FOLD bit (16)
 };
 // want_P / want_var < 0: the production (first listed) instance of the shape.
 const MlpInstance* find_mlp_instance(int D, int De, int Dh, int want_P, int want_var);

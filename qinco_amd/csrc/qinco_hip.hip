@@ -22,14 +22,16 @@ using namespace qinco;
 // ---------------------------------------------------------------------------------------------
 // per-shape launchers (shapes.def)
 // ---------------------------------------------------------------------------------------------
-#define QINCO_SHAPE(D, DE, DH, P, VAR) \
-  extern "C" hipError_t qinco_mlp_launch_##D##_##DE##_##DH##_##P##_##VAR(const qinco::MlpArgs*, hipStream_t);
+#define QINCO_SHAPE(D, DE, DH, P, VAR)                                                                        \
+  extern "C" hipError_t qinco_mlp_launch_##D##_##DE##_##DH##_##P##_##VAR(const qinco::MlpArgs*, hipStream_t); \
+  extern "C" hipError_t qinco_xproj_launch_##D##_##DE##_##DH##_##P##_##VAR(const qinco::XprojArgs*, hipStream_t);
 #include "shapes.def"
 #undef QINCO_SHAPE
 
 namespace qinco {
 static const MlpInstance g_instances[] = {
-#define QINCO_SHAPE(d, de, dh, p, var) {d, de, dh, p, var, &qinco_mlp_launch_##d##_##de##_##dh##_##p##_##var},
+#define QINCO_SHAPE(d, de, dh, p, var) \
+  {d, de, dh, p, var, &qinco_mlp_launch_##d##_##de##_##dh##_##p##_##var, &qinco_xproj_launch_##d##_##de##_##dh##_##p##_##var},
 #include "shapes.def"
 #undef QINCO_SHAPE
 };
@@ -81,6 +83,12 @@ struct qinco_handle_s {
   float std_ = 1.f;
   std::vector<float*> codebook, sub_codebook, cnorm, sub_cnorm;
   std::vector<f32x4*> cb_stream, sub_stream;   // the same codebooks as MFMA A-operand fragments (table kernels)
+  // FOLD: per-codeword head table T (K, De) and the xhat half of the concat weight as fragments, per step
+  bool fold = false;
+  std::vector<float*> ttab;
+  std::vector<f32x4*> wx_stream;
+  float* uproj = nullptr;      // (max_batch * B, De) scratch: U_g = W_cat[:, De:] xhat_g
+  float* duproj = nullptr;     // decode counterpart (dec_cap, De)
   std::vector<f32x4*> wstream;
   int* kvals = nullptr;
   int* err_flag = nullptr;
@@ -239,12 +247,14 @@ static int upload_with_norms(qinco_handle_s* h, const float* cb, int K, int D, f
 static int ensure_scratch(qinco_handle_s* h) {
   const qinco_desc& d = h->d;
   if (h->cap_n == d.max_batch && h->cap_A == h->A && h->cap_B == h->B) return 0;
-  void* old[] = {h->xn, h->xhat[0], h->xhat[1], h->hist[0], h->hist[1], h->top_ids, h->cand, h->dist, h->ivf_best};
+  void* old[] = {h->xn, h->xhat[0], h->xhat[1], h->hist[0], h->hist[1], h->top_ids, h->cand, h->dist, h->ivf_best,
+                 h->uproj};
   HIP_TRY(hipDeviceSynchronize());
   for (void* p : old) dev_free(h, p);
   h->xn = h->xhat[0] = h->xhat[1] = h->cand = h->dist = nullptr;
   h->hist[0] = h->hist[1] = h->top_ids = nullptr;
   h->ivf_best = nullptr;
+  h->uproj = nullptr;
   h->cap_n = 0;
   const size_t n = (size_t)d.max_batch;
   const size_t Bm = (size_t)(h->B < d.K ? h->B : d.K);   // widest beam (beam_0 = min(B, K))
@@ -261,9 +271,52 @@ static int ensure_scratch(qinco_handle_s* h) {
   if ((rc = dev_alloc(h, &h->cand, n * Bm * Ae * d.D))) return rc;
   if ((rc = dev_alloc(h, &h->dist, n * Bm * Ae))) return rc;
   if (d.ivf_K > 0 && (rc = dev_alloc(h, &h->ivf_best, n))) return rc;
+  if (h->fold && (rc = dev_alloc(h, &h->uproj, n * Bm * d.De))) return rc;
   h->cap_n = d.max_batch;
   h->cap_A = h->A;
   h->cap_B = h->B;
+  return 0;
+}
+
+// FOLD (mlp_kernel.hpp): the row-independent head of the MLP.
+//   T[k] = z_k + (b + W_cat[:, :De] z_k),  z_k = in_proj(c_k) (or c_k when De == D)     -- per codeword
+//   wx   = W_cat[:, De:] as MFMA fragments (ob, ib, q)                                   -- for xproj_kernel
+static int build_fold_tables(qinco_handle_s* h, const qinco_weights* w, int m) {
+  const qinco_desc& d = h->d;
+  const int D = d.D, De = d.De, K = d.K, I = De + D;
+  const float* cb = w->codebook[m];
+  const float* win = (De != D) ? w->in_proj[m] : nullptr;
+  const float* wc = w->cat_w[m];
+  const float* bc = w->cat_b[m];
+  std::vector<float> T((size_t)K * De), z(De);
+  for (int k = 0; k < K; ++k) {
+    const float* c = cb + (size_t)k * D;
+    for (int i = 0; i < De; ++i) {
+      if (win) {
+        float a = 0.f;
+        for (int j = 0; j < D; ++j) a = fmaf(win[(size_t)i * D + j], c[j], a);
+        z[i] = a;
+      } else {
+        z[i] = c[i];
+      }
+    }
+    for (int i = 0; i < De; ++i) {
+      float a = bc[i];
+      const float* wr = wc + (size_t)i * I;
+      for (int j = 0; j < De; ++j) a = fmaf(wr[j], z[j], a);
+      T[(size_t)k * De + i] = z[i] + a;
+    }
+  }
+  int rc = upload(h, &h->ttab[m], T.data(), T.size());
+  if (rc) return rc;
+  std::vector<float> s;
+  s.reserve((size_t)De * D);
+  for (int ob = 0; ob < De / 32; ++ob)
+    for (int ib = 0; ib < D / 32; ++ib)
+      for (int q = 0; q < 4; ++q) put_frag(s, wc + De, I, ob, ib, q);
+  float* ds = nullptr;
+  if ((rc = upload(h, &ds, s.data(), s.size()))) return rc;
+  h->wx_stream[m] = reinterpret_cast<f32x4*>(ds);
   return 0;
 }
 
@@ -279,6 +332,8 @@ static int ensure_decode_scratch(qinco_handle_s* h, int64_t n) {
   dev_free(h, h->dxhat[0]);
   dev_free(h, h->dxhat[1]);
   dev_free(h, h->codes_t);
+  dev_free(h, h->duproj);
+  h->duproj = nullptr;
   h->dxhat[0] = h->dxhat[1] = nullptr;
   h->codes_t = nullptr;
   h->dec_cap = 0;
@@ -286,6 +341,7 @@ static int ensure_decode_scratch(qinco_handle_s* h, int64_t n) {
   for (int i = 0; i < 2; ++i)
     if ((rc = dev_alloc(h, &h->dxhat[i], (size_t)want * h->d.D))) return rc;
   if ((rc = dev_alloc(h, &h->codes_t, (size_t)want * h->d.M))) return rc;
+  if (h->fold && (rc = dev_alloc(h, &h->duproj, (size_t)want * h->d.De))) return rc;
   h->dec_cap = want;
   return 0;
 }
@@ -333,7 +389,8 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   h->inst = fn;
   h->std_ = w->data_std;
   const int kRing = fn ? fn->P : 8;
-  h->sd = stream_dims(d.D, d.De, d.Dh, kRing);
+  h->fold = fn && (fn->var & 16);
+  h->sd = stream_dims(d.D, d.De, d.Dh, kRing, h->fold);
   int rc = 0;
   auto bail = [&](int code) {
     qinco_destroy(h);
@@ -349,6 +406,8 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   h->wstream.assign(d.M, nullptr);
   h->cb_stream.assign(d.M, nullptr);
   h->sub_stream.assign(d.M, nullptr);
+  h->ttab.assign(d.M, nullptr);
+  h->wx_stream.assign(d.M, nullptr);
   h->K0 = d.ivf_K > 0 ? d.ivf_K : d.K;
   std::vector<int> kv(d.M, d.K);
   kv[0] = h->K0;
@@ -378,13 +437,16 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
     const StreamDims& sd = h->sd;
     std::vector<float> s;
     s.reserve((size_t)(sd.total(d.L) + kRing) * 256);
-    if (sd.PROJ) {
-      if (!w->in_proj[m] || !w->out_proj[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: in/out_proj[%d] is null", m));
-      pack_kouter(s, w->in_proj[m], d.De, d.D, sd.T_IN);
-    }
+    if (sd.PROJ && (!w->in_proj[m] || !w->out_proj[m]))
+      return bail(fail(QINCO_ERR_INVALID, "qinco_create: in/out_proj[%d] is null", m));
     if (!w->cat_w[m] || !w->cat_b[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: concat weights[%d] null", m));
-    pack_bias(s, w->cat_b[m], d.De, sd.T_BIAS);
-    pack_kouter(s, w->cat_w[m], d.De, d.De + d.D, sd.T_CAT);
+    if (h->fold) {
+      if ((rc = build_fold_tables(h, w, m))) return bail(rc);
+    } else {
+      if (sd.PROJ) pack_kouter(s, w->in_proj[m], d.De, d.D, sd.T_IN);
+      pack_bias(s, w->cat_b[m], d.De, sd.T_BIAS);
+      pack_kouter(s, w->cat_w[m], d.De, d.De + d.D, sd.T_CAT);
+    }
     for (int l = 0; l < d.L; ++l) {
       const float* up = w->up[(size_t)m * d.L + l];
       const float* dn = w->down[(size_t)m * d.L + l];
@@ -442,9 +504,11 @@ static unsigned ew_grid(long total) {
   return (unsigned)g;
 }
 
-static int launch_mlp(qinco_handle_s* h, const MlpArgs& a, hipStream_t st) {
+// One step's fused MLP over a.R rows.  FOLD: a.uproj names the scratch for U (encode: h->uproj, decode: h->duproj);
+// it is filled here by xproj_kernel for the R/A groups of this launch, and T comes from the step's table.
+static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->prof) {
+  if (h->prof) {   // the bracket covers xproj + mlp: all the work the algorithmic FLOP count stands for
     if (h->ev_used == h->ev_pool.size()) {
       hipEvent_t a0, a1;
       HIP_TRY(hipEventCreate(&a0));
@@ -455,6 +519,15 @@ static int launch_mlp(qinco_handle_s* h, const MlpArgs& a, hipStream_t st) {
     e1 = h->ev_pool[h->ev_used].second;
     h->ev_used++;
     HIP_TRY(hipEventRecord(e0, st));
+  }
+  if (h->fold) {
+    XprojArgs xa{};
+    xa.wx = h->wx_stream[m];
+    xa.xhat = a.xhat;
+    xa.uproj = const_cast<float*>(a.uproj);
+    xa.G = a.R / a.A;
+    HIP_TRY(h->inst->xproj(&xa, st));
+    a.ttab = h->ttab[m];
   }
   HIP_TRY(h->inst->fn(&a, st));
   if (h->prof) {
@@ -568,7 +641,8 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
     a.cand_out = h->cand;
     a.dist_out = h->dist;
     a.add_c = d.qinco1_mode ? 0 : 1;
-    if ((rc = launch_mlp(h, a, st))) return rc;
+    a.uproj = h->uproj;
+    if ((rc = launch_mlp(h, a, m, st))) return rc;
     const int C = F * Ae;
     const int T = Fout_cfg < C ? Fout_cfg : C;
     size_t lds = (size_t)4 * C * sizeof(float);
@@ -647,7 +721,8 @@ static int decode_chunk(qinco_handle_s* h, const void* codes, int code_dtype, in
     a.cand_out = h->dxhat[cur ^ 1];  // xhat += f_m(c, xhat)  (qinco_inference.py:72-74)
     a.dist_out = nullptr;
     a.add_c = d.qinco1_mode ? 0 : 1;
-    int rc = launch_mlp(h, a, st);
+    a.uproj = h->duproj;
+    int rc = launch_mlp(h, a, m, st);
     if (rc) return rc;
     cur ^= 1;
   }

@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Race / delivery-mechanism stress test (GPU box).  The fused-MLP kernel variants differ only in HOW weight
+fragments reach the MFMA (register ring of plain loads, per-wave LDS-DMA rings, workgroup-shared ring with barriers);
+their arithmetic is identical, so codes AND reconstructions must agree bit for bit on a large batch.  Any ordering bug
+in the hand-counted vmcnt / barrier protocol shows up as a mismatch.  The FOLD production kernel (different fp32
+association) is checked for run-to-run determinism and near-total code agreement with them.
+    python scripts/gpu_stress.py [C2 C1] [--n 32768]
+"""
+import argparse
+import os
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def worker(wl, n, out):
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    from qinco_amd.config import BASELINE_CONFIGS
+    cfg = BASELINE_CONFIGS[wl]
+    sd = synth_state_dict(cfg, 1236)
+    x = synth_vectors(cfg, sd, n, seed=123)
+    eng = QincoEngine(cfg, sd, max_batch=8192)
+    c1, h1 = eng.encode(x, return_xhat=True)
+    c2, h2 = eng.encode(x, return_xhat=True)
+    assert np.array_equal(c1, c2) and np.array_equal(h1, h2), "run-to-run nondeterminism"
+    np.savez(out, codes=c1, xhat=h1)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
+        worker(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+        sys.exit(0)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workloads", nargs="*", default=["C2", "C1"])
+    ap.add_argument("--n", type=int, default=32768)
+    args = ap.parse_args()
+    ok = True
+    for wl in args.workloads:
+        res = {}
+        with tempfile.TemporaryDirectory() as d:
+            for var in ["", "48,76", "36,12", "8,0"]:
+                env = dict(os.environ)
+                if var:
+                    env["QINCO_MLP_VARIANT"] = var
+                out = os.path.join(d, f"v_{var.replace(',', '_')}.npz")
+                subprocess.check_call([sys.executable, __file__, "--worker", wl, str(args.n), out], env=env)
+                res[var or "production"] = dict(np.load(out))
+        base = res["48,76"]
+        for k in ("36,12", "8,0"):
+            same = np.array_equal(res[k]["codes"], base["codes"]) and np.array_equal(res[k]["xhat"], base["xhat"])
+            print(f"{wl}: variant {k} vs 48,76 bitwise equal: {same}")
+            ok &= same
+        diff = int((res["production"]["codes"] != base["codes"]).any(axis=1).sum())
+        print(f"{wl}: production (FOLD) vs 48,76: {diff} of {args.n} code rows differ (different fp32 association)")
+        ok &= diff <= args.n // 200
+    print("STRESS", "OK" if ok else "FAILED")
+    sys.exit(0 if ok else 1)

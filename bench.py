@@ -161,8 +161,11 @@ def main():
         rows_per_launch = flops_per_launch / cfg.mlp_flops_per_row()
         # FOLD (mlp_kernel.hpp): the row-independent head of the MLP is not recomputed per row, so the MFMA executes
         # fewer FLOPs than the reference's algorithm counts; `achieved` stays algorithmic, this is the executed share.
-        head = (2.0 * cfg.D * cfg.De if cfg.De != cfg.D else 0.0) + 2.0 * (cfg.De + cfg.D) * cfg.De
-        executed = 1.0 - (head - 2.0 * cfg.D * cfg.De / (cfg.A or cfg.K)) / cfg.mlp_flops_per_row()
+        Ae = cfg.A or cfg.K
+        head = (2.0 * cfg.D * cfg.De if cfg.De != cfg.D else 0.0) + 2.0 * (cfg.De + cfg.D) * cfg.De   # FOLD
+        head += 2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0                                            # FOLD2
+        per_group = 2.0 * cfg.D * cfg.De + (2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0)               # xproj
+        executed = 1.0 - (head - per_group / Ae) / cfg.mlp_flops_per_row()
         out = {
             "metric": "encode vectors/sec (BigANN-shaped d=128 8x8, beam=%d)" % cfg.B,
             "value": value, "unit": "vectors/s", "n_gpus": world, "steps": K, "warmup": args.warmup,

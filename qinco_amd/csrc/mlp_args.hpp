@@ -15,13 +15,17 @@ struct StreamDims {
   int NDB, NEB, NHB;
   bool PROJ;
   int T_IN, T_BIAS, T_CAT, T_UP, T_DOWN, T_OUT;
-  constexpr long total(int L) const { return (long)T_IN + T_BIAS + T_CAT + (long)L * (T_UP + T_DOWN) + T_OUT; }
+  bool FOLD2;   // the first FFN block's up-projection is not in the stream either (mlp_kernel.hpp FOLD2)
+  constexpr long total(int L) const {
+    return (long)T_IN + T_BIAS + T_CAT + (long)L * (T_UP + T_DOWN) - ((FOLD2 && L > 0) ? T_UP : 0) + T_OUT;
+  }
 };
 
 // fold = true: in_proj / bias / concat are not in the stream (the kernel starts from z = T[cid] + U[group], see
 // mlp_kernel.hpp FOLD).
-constexpr StreamDims stream_dims(int D, int DE, int DH, int P, bool fold = false) {
+constexpr StreamDims stream_dims(int D, int DE, int DH, int P, bool fold = false, bool fold2 = false) {
   StreamDims s{};
+  s.FOLD2 = fold2;
   s.NDB = D / 32;
   s.NEB = DE / 32;
   s.NHB = DH / 32;
@@ -50,6 +54,8 @@ struct MlpArgs {
   int add_c;              // 1: + c (QINCo2), 0: qinco1_mode (res_codeword_coeff = 0)
   const float* ttab;      // FOLD: (K, De) per-codeword table  T_k = z_k + W_cat[:, :De] z_k + b,  z_k = in_proj(c_k)
   const float* uproj;     // FOLD: (R/A, De) per-group  U_g = W_cat[:, De:] xhat_g   (xproj_kernel)
+  const float* ptab;      // FOLD2: (K, Dh)  P_k = W_up[0] T_k
+  const float* qproj;     // FOLD2: (R/A, Dh) Q_g = W_up[0] U_g
 };
 
 struct XprojArgs {
@@ -57,6 +63,8 @@ struct XprojArgs {
   const float* xhat;      // (G, D)
   float* uproj;           // (G, De)
   long G;
+  const f32x4* wq;        // FOLD2: W_up[0] (Dh x De) as fragments in (ob, ib, q) order, or nullptr
+  float* qproj;           // FOLD2: (G, Dh)
 };
 
 }  // namespace qinco

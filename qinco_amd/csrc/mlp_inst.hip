@@ -18,6 +18,6 @@ extern "C" __attribute__((visibility("hidden")))
 hipError_t QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::XprojArgs* a, hipStream_t stream) {
   if (a->G <= 0) return hipSuccess;
   const unsigned grid = (unsigned)((a->G + 127) / 128);
-  hipLaunchKernelGGL((qinco::xproj_kernel<QD, QDE>), dim3(grid), dim3(256), 0, stream, *a);
+  hipLaunchKernelGGL((qinco::xproj_kernel<QD, QDE, QDH>), dim3(grid), dim3(256), 0, stream, *a);
   return hipGetLastError();
 }

@@ -29,6 +29,10 @@
 //             qinco_create), W_cat[:, De:] xhat depends only on the (vector, beam) group (U, one small MFMA GEMM per
 //             step: xproj_kernel).  The kernel starts from z = T[cid] + U[group]: -4.9 % MFMA work at C2.
 //             Same real-number result as QConcat.forward; the fp32 association differs ((b + Wz z) + Wx xhat).
+//   32 FOLD2  (with FOLD) the first FFN block's up-projection is linear in z = T + U as well:
+//             W_up[0] z = P[cid] + Q[group] with P = W_up[0] T (table) and Q = W_up[0] U (same xproj launch), so the
+//             kernel starts with y = relu(P[cid] + Q[group]) and the first down-projection: -2.9 % more at C2, -20 %
+//             for the two-block qinco2-S.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <utility>
@@ -92,14 +96,16 @@ QINCO_INL void pin_a(f32x16& v) { asm volatile("" : "+a"(v)); }
 template <int D, int DE, int DH, int P, int VAR>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   constexpr bool FOLD = (VAR & 16) != 0;
-  constexpr StreamDims SL = stream_dims(D, DE, DH, P, FOLD);
+  constexpr bool FOLD2 = (VAR & 32) != 0;
+  static_assert(!FOLD2 || (FOLD && (VAR & 8)), "FOLD2 needs FOLD and the pinned plan");
+  constexpr StreamDims SL = stream_dims(D, DE, DH, P, FOLD, FOLD2);
   constexpr int NDB = SL.NDB, NEB = SL.NEB, NHB = SL.NHB;
   constexpr bool PROJ = SL.PROJ;
   constexpr int NYB = NHB > NEB ? NHB : NEB;
   constexpr bool LDSR = (VAR & 4) != 0;
   constexpr bool PINNED = (VAR & 8) != 0;
   constexpr bool SHR = (VAR & 64) != 0;
-  static_assert((VAR & ~(4 | 8 | 16 | 64)) == 0, "unknown VAR bits");
+  static_assert((VAR & ~(4 | 8 | 16 | 32 | 64)) == 0, "unknown VAR bits");
   static_assert(!SHR || (LDSR && P % 12 == 0 && P / 4 >= 5), "shared ring: P multiple of 12 (3 register sets, 4 issuers)");
   static_assert(!LDSR || SHR || (P % 3 == 0 && P >= 6 && P <= 39), "per-wave LDS rings: 4 x P KiB must fit 160 KiB");
 
@@ -212,6 +218,15 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     const float* tptr = a.ttab + (long)cid * DE + half * 4;
     const float* uptr = a.uproj + g * DE + half * 4;
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = load_block(tptr + ob * 32) + load_block(uptr + ob * 32); });
+    if constexpr (FOLD2) {
+      const float* pptr = a.ptab + (long)cid * DH + half * 4;
+      const float* qptr = a.qproj + g * DH + half * 4;
+      static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
+        y[ob] = load_block(pptr + ob * 32) + load_block(qptr + ob * 32);
+        relu16(y[ob]);
+        pin_a(y[ob]);
+      });
+    }
   } else {
     // ---- A: z = in_proj(c)  (K-outer; c blocks streamed from the codebook, next block prefetched) ---------
     if constexpr (PROJ) {
@@ -275,9 +290,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     //   up:   y[ob-1] = relu(t_prev)  (16 v_max_i32 + 16 v_accvgpr_write)
     //   down: z[ob-1] += t_prev       (16 v_add_f32)
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA { pin_v(z[ob]); });
-#pragma unroll 1
-    for (int l = 0; l < a.L; ++l) {
-      f32x16 t[2];
+    f32x16 t[2];
+    auto up_phase = [&]() QINCO_LAMBDA {
       static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
         t[ob & 1] = zero16();
         static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
@@ -299,6 +313,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
       pin_a(y[NHB - 1]);
       skip_pad.template operator()<NHB * NEB * 4, SL.T_UP>();
       wp += SL.T_UP * 64;
+    };
+    auto down_phase = [&]() QINCO_LAMBDA {
       static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
         t[ob & 1] = zero16();
         static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
@@ -319,6 +335,12 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
       pin_v(z[NEB - 1]);
       skip_pad.template operator()<NEB * NHB * 4, SL.T_DOWN>();
       wp += SL.T_DOWN * 64;
+    };
+    if constexpr (FOLD2) down_phase();   // block 0 (needs L >= 1: the host never picks FOLD2 for L == 0)
+#pragma unroll 1
+    for (int l = FOLD2 ? 1 : 0; l < a.L; ++l) {
+      up_phase();
+      down_phase();
     }
   } else {
 #pragma unroll 1
@@ -401,7 +423,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
 
 // U[g] = W_cat[:, De:] . xhat_g for every (vector, beam) group (FOLD).  Same transposed-MFMA form: a wave keeps its 32
 // groups' xhat as B operands and streams the (De x D) weight fragments (L2 resident) as A operands.
-template <int D, int DE>
+template <int D, int DE, int DH>
 __global__ void __launch_bounds__(256) xproj_kernel(XprojArgs a) {
   constexpr int NDB = D / 32, NEB = DE / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -417,6 +439,7 @@ __global__ void __launch_bounds__(256) xproj_kernel(XprojArgs a) {
   for (int ib = 0; ib < NDB; ++ib) xt[ib] = load_block(xp + ib * 32);
   const f32x4* wp = a.wx + lane;
   float* up = a.uproj + g * DE + half * 4;
+  f32x16 u[NEB];
 #pragma unroll
   for (int ob = 0; ob < NEB; ++ob) {
     f32x16 acc = zero16();
@@ -428,11 +451,35 @@ __global__ void __launch_bounds__(256) xproj_kernel(XprojArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = QINCO_MFMA(w[e], xt[ib][4 * q + e], acc);
       }
+    u[ob] = acc;
     if (valid) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 t = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
         *reinterpret_cast<f32x4*>(up + ob * 32 + 8 * q) = t;
+      }
+    }
+  }
+  if (a.wq) {   // FOLD2: Q = W_up[0] . U, chained on the U blocks still in registers (C layout = B layout)
+    const f32x4* wq = a.wq + lane;
+    float* qp = a.qproj + g * DH + half * 4;
+#pragma unroll
+    for (int ob = 0; ob < DH / 32; ++ob) {
+      f32x16 acc = zero16();
+#pragma unroll
+      for (int ib = 0; ib < NEB; ++ib)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 w = wq[((ob * NEB + ib) * 4 + q) * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = QINCO_MFMA(w[e], u[ib][4 * q + e], acc);
+        }
+      if (valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 t = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          *reinterpret_cast<f32x4*>(qp + ob * 32 + 8 * q) = t;
+        }
       }
     }
   }

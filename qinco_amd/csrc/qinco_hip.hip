@@ -84,11 +84,11 @@ struct qinco_handle_s {
   std::vector<float*> codebook, sub_codebook, cnorm, sub_cnorm;
   std::vector<f32x4*> cb_stream, sub_stream;   // the same codebooks as MFMA A-operand fragments (table kernels)
   // FOLD: per-codeword head table T (K, De) and the xhat half of the concat weight as fragments, per step
-  bool fold = false;
-  std::vector<float*> ttab;
-  std::vector<f32x4*> wx_stream;
-  float* uproj = nullptr;      // (max_batch * B, De) scratch: U_g = W_cat[:, De:] xhat_g
-  float* duproj = nullptr;     // decode counterpart (dec_cap, De)
+  bool fold = false, fold2 = false;
+  std::vector<float*> ttab, ptab;            // T (K, De);  FOLD2: P = W_up[0] T (K, Dh)
+  std::vector<f32x4*> wx_stream, wq_stream;  // W_cat[:, De:] and (FOLD2) W_up[0] as fragments for xproj_kernel
+  float* uproj = nullptr;      // (max_batch * B, De [+ Dh]) scratch: U_g = W_cat[:, De:] xhat_g  [then Q_g = W_up[0] U_g]
+  float* duproj = nullptr;     // decode counterpart (dec_cap, De [+ Dh])
   std::vector<f32x4*> wstream;
   int* kvals = nullptr;
   int* err_flag = nullptr;
@@ -271,7 +271,7 @@ static int ensure_scratch(qinco_handle_s* h) {
   if ((rc = dev_alloc(h, &h->cand, n * Bm * Ae * d.D))) return rc;
   if ((rc = dev_alloc(h, &h->dist, n * Bm * Ae))) return rc;
   if (d.ivf_K > 0 && (rc = dev_alloc(h, &h->ivf_best, n))) return rc;
-  if (h->fold && (rc = dev_alloc(h, &h->uproj, n * Bm * d.De))) return rc;
+  if (h->fold && (rc = dev_alloc(h, &h->uproj, n * Bm * (d.De + (h->fold2 ? d.Dh : 0))))) return rc;
   h->cap_n = d.max_batch;
   h->cap_A = h->A;
   h->cap_B = h->B;
@@ -317,6 +317,29 @@ static int build_fold_tables(qinco_handle_s* h, const qinco_weights* w, int m) {
   float* ds = nullptr;
   if ((rc = upload(h, &ds, s.data(), s.size()))) return rc;
   h->wx_stream[m] = reinterpret_cast<f32x4*>(ds);
+  if (h->fold2) {  // P_k = W_up[0] T_k  and  W_up[0] as fragments (ob, ib, q) for Q_g = W_up[0] U_g
+    const int Dh = d.Dh;
+    const float* up0 = w->up[(size_t)m * d.L];
+    if (!up0) return fail(QINCO_ERR_INVALID, "qinco_create: FFN weights[%d][0] null", m);
+    std::vector<float> Pt((size_t)K * Dh);
+    for (int k = 0; k < K; ++k)
+      for (int i = 0; i < Dh; ++i) {
+        float a = 0.f;
+        const float* wr = up0 + (size_t)i * De;
+        const float* t = T.data() + (size_t)k * De;
+        for (int j = 0; j < De; ++j) a = fmaf(wr[j], t[j], a);
+        Pt[(size_t)k * Dh + i] = a;
+      }
+    if ((rc = upload(h, &h->ptab[m], Pt.data(), Pt.size()))) return rc;
+    std::vector<float> sq;
+    sq.reserve((size_t)Dh * De);
+    for (int ob = 0; ob < Dh / 32; ++ob)
+      for (int ib = 0; ib < De / 32; ++ib)
+        for (int q = 0; q < 4; ++q) put_frag(sq, up0, De, ob, ib, q);
+    float* dq = nullptr;
+    if ((rc = upload(h, &dq, sq.data(), sq.size()))) return rc;
+    h->wq_stream[m] = reinterpret_cast<f32x4*>(dq);
+  }
   return 0;
 }
 
@@ -341,7 +364,7 @@ static int ensure_decode_scratch(qinco_handle_s* h, int64_t n) {
   for (int i = 0; i < 2; ++i)
     if ((rc = dev_alloc(h, &h->dxhat[i], (size_t)want * h->d.D))) return rc;
   if ((rc = dev_alloc(h, &h->codes_t, (size_t)want * h->d.M))) return rc;
-  if (h->fold && (rc = dev_alloc(h, &h->duproj, (size_t)want * h->d.De))) return rc;
+  if (h->fold && (rc = dev_alloc(h, &h->duproj, (size_t)want * (h->d.De + (h->fold2 ? h->d.Dh : 0))))) return rc;
   h->dec_cap = want;
   return 0;
 }
@@ -389,8 +412,16 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   h->inst = fn;
   h->std_ = w->data_std;
   const int kRing = fn ? fn->P : 8;
+  if (fn && (fn->var & 32) && d.L == 0) {  // FOLD2 peels FFN block 0: a model without FFN blocks takes the plain FOLD kernel
+    fn = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~32);
+    if (!fn || (fn->var & 32))
+      return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: L = 0 needs a kernel instance without FOLD2 for (D=%d, De=%d, Dh=%d)", d.D,
+                  d.De, d.Dh);
+    h->inst = fn;
+  }
   h->fold = fn && (fn->var & 16);
-  h->sd = stream_dims(d.D, d.De, d.Dh, kRing, h->fold);
+  h->fold2 = fn && (fn->var & 32);
+  h->sd = stream_dims(d.D, d.De, d.Dh, kRing, h->fold, h->fold2);
   int rc = 0;
   auto bail = [&](int code) {
     qinco_destroy(h);
@@ -407,7 +438,9 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   h->cb_stream.assign(d.M, nullptr);
   h->sub_stream.assign(d.M, nullptr);
   h->ttab.assign(d.M, nullptr);
+  h->ptab.assign(d.M, nullptr);
   h->wx_stream.assign(d.M, nullptr);
+  h->wq_stream.assign(d.M, nullptr);
   h->K0 = d.ivf_K > 0 ? d.ivf_K : d.K;
   std::vector<int> kv(d.M, d.K);
   kv[0] = h->K0;
@@ -451,7 +484,7 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
       const float* up = w->up[(size_t)m * d.L + l];
       const float* dn = w->down[(size_t)m * d.L + l];
       if (!up || !dn) return bail(fail(QINCO_ERR_INVALID, "qinco_create: FFN weights[%d][%d] null", m, l));
-      pack_obouter(s, up, d.Dh, d.De, sd.T_UP);
+      if (!(h->fold2 && l == 0)) pack_obouter(s, up, d.Dh, d.De, sd.T_UP);
       pack_obouter(s, dn, d.De, d.Dh, sd.T_DOWN);
     }
     if (sd.PROJ) pack_obouter(s, w->out_proj[m], d.D, d.De, sd.T_OUT);
@@ -526,6 +559,12 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st) {
     xa.xhat = a.xhat;
     xa.uproj = const_cast<float*>(a.uproj);
     xa.G = a.R / a.A;
+    if (h->fold2) {  // Q lives behind U in the same scratch
+      xa.wq = h->wq_stream[m];
+      xa.qproj = xa.uproj + (size_t)xa.G * h->d.De;
+      a.qproj = xa.qproj;
+      a.ptab = h->ptab[m];
+    }
     HIP_TRY(h->inst->xproj(&xa, st));
     a.ttab = h->ttab[m];
   }

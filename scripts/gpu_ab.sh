@@ -4,10 +4,10 @@ set -x
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 V=${1:-"36,28"}
 QINCO_MLP_VARIANT=$V timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest_gpu_variant.log 2>&1; tail -4 $O/pytest_gpu_variant.log
-for v in "48,76" "$V" "48,76" "$V"; do
+for v in "48,92" "$V" "48,92" "$V"; do
   echo "== C2 variant $v"; QINCO_MLP_VARIANT=$v timeout 600 python bench.py --steps 3 --warmup 1 --batch 8192 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['achieved'], d['roofline']['frac'])"
 done
-for v in "48,76" "$V"; do
+for v in "48,92" "$V"; do
   echo "== C1 variant $v"; QINCO_MLP_VARIANT=$v timeout 600 python scripts/bench_extra.py C1 --steps 3 2>/dev/null | grep encode | cut -c1-220
 done
 cd /tmp

@@ -44,7 +44,7 @@ if __name__ == "__main__":
     for wl in args.workloads:
         res = {}
         with tempfile.TemporaryDirectory() as d:
-            for var in ["", "48,76", "36,12", "8,0"]:
+            for var in ["", "48,92", "48,76", "36,12", "8,0"]:
                 env = dict(os.environ)
                 if var:
                     env["QINCO_MLP_VARIANT"] = var
@@ -56,8 +56,9 @@ if __name__ == "__main__":
             same = np.array_equal(res[k]["codes"], base["codes"]) and np.array_equal(res[k]["xhat"], base["xhat"])
             print(f"{wl}: variant {k} vs 48,76 bitwise equal: {same}")
             ok &= same
-        diff = int((res["production"]["codes"] != base["codes"]).any(axis=1).sum())
-        print(f"{wl}: production (FOLD) vs 48,76: {diff} of {args.n} code rows differ (different fp32 association)")
-        ok &= diff <= args.n // 200
+        for k in ("production", "48,92"):
+            diff = int((res[k]["codes"] != base["codes"]).any(axis=1).sum())
+            print(f"{wl}: {k} (folded head) vs 48,76: {diff} of {args.n} code rows differ (different fp32 association)")
+            ok &= diff <= args.n // 200
     print("STRESS", "OK" if ok else "FAILED")
     sys.exit(0 if ok else 1)

@@ -285,3 +285,15 @@ def test_every_kernel_instance_matches_oracle(shape):
     ref = oracle(want.T, step="decode")
     assert np.abs(dec - ref).max() / np.abs(ref).max() < REL_TOL
     eng.close()
+
+
+def test_model_without_ffn_blocks_uses_fallback_instance():
+    """L = 0 (no residual blocks): FOLD2 cannot peel a first block; the library must pick the FOLD-only instance."""
+    from qinco_amd import QincoConfig, QincoEngine, synth_state_dict, synth_vectors
+    cfg = QincoConfig(D=32, M=3, K=256, L=0, de=64, dh=96, A=8, B=2)
+    sd = synth_state_dict(cfg, 5)
+    x = synth_vectors(cfg, sd, 100, seed=3)
+    eng = QincoEngine(cfg, sd, max_batch=64)
+    want = make_oracle(cfg, sd)(x, step="encode").T
+    assert (eng.encode(x) != want).any(axis=1).sum() <= 1
+    eng.close()

@@ -113,6 +113,24 @@ QINCO_API double qinco_flops_per_vector_decode(qinco_handle h);
 /* 1 if a fused-MLP kernel instance exists for (D, De, Dh). */
 QINCO_API int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh);
 
+/* ---- look-up decoders downstream of the hot path --------------------------------------------
+ * out[n] = sum_j tables[j][ codes[n][a[j]] * mul + (b[j] >= 0 ? codes[n][b[j]] : 0) ]   (fp32, summed in j order)
+ *   additive-quantiser decode  reconstruct_from_fixed_codebooks (qinco/search/search_utils.py:105-115):
+ *       J = M, a[j] = j, b[j] = -1, mul = 1, Kt = K
+ *   pairwise decoder  PairwiseDecoderIVF.forward + map_codes (qinco/search/pairwise_decoder.py:88-93, 126-130):
+ *       J = M_target, a = combine_mvals_m[0], b = combine_mvals_m[1], mul = K_base, Kt = K_base^2; the caller
+ *       appends ivf_code_map[ivf_codes] to the code columns first, like map_codes does.
+ * tables: host pointer to (J, Kt, D) fp32, copied to the device at create.  J <= 64, D % 4 == 0. */
+typedef struct qinco_lut_s* qinco_lut;
+QINCO_API int qinco_lut_create(const float* tables, int32_t J, int64_t Kt, int32_t D, const int32_t* a, const int32_t* b,
+                               int64_t mul, qinco_lut* out);
+QINCO_API int qinco_lut_destroy(qinco_lut lut);
+/* codes: device (n, Mc) of code_dtype; out: device (n, D) fp32; enqueued on `stream`, not synchronised. */
+QINCO_API int qinco_lut_decode(qinco_lut lut, const void* codes, int code_dtype, int32_t Mc, int64_t n, float* out,
+                               void* stream);
+/* host buffers; synchronous; QINCO_ERR_RANGE if a look-up index falls outside its table. */
+QINCO_API int qinco_lut_decode_host(qinco_lut lut, const void* codes, int code_dtype, int32_t Mc, int64_t n, float* out);
+
 QINCO_API const char* qinco_last_error(void);
 QINCO_API const char* qinco_version(void);
 

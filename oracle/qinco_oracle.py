@@ -208,3 +208,31 @@ def mse(x: np.ndarray, xhat: np.ndarray, mse_scale: float = 1.0) -> float:
     """AnyVectMSE (qinco/metrics.py:41-58): sum_i |x_i - xhat_i|^2 * mse_scale / N."""
     diff = np.asarray(x, dtype=np.float64) - np.asarray(xhat, dtype=np.float64)
     return float((diff * diff).sum() * mse_scale / len(x))
+
+
+# --------------------------------------------------------------------------------------------------
+# look-up decoders downstream of the path (SURVEY.md 8f4).  PARITY UNPINNED: the reference modules that hold them
+# (qinco/search/search_utils.py, qinco/search/pairwise_decoder.py) import faiss / torcheval, which are not installed
+# here, so no golden vectors could be produced by the reference itself; these restate the cited lines directly.
+# --------------------------------------------------------------------------------------------------
+def reconstruct_from_fixed_codebooks(codes: np.ndarray, codebooks: np.ndarray) -> np.ndarray:
+    """search_utils.py:105-115."""
+    M = codes.shape[1]
+    assert codebooks.shape[0] == M
+    recons = codebooks[0, codes[:, 0]].astype(F32).copy()
+    for m in range(1, M):
+        recons += codebooks[m, codes[:, m]]
+    return recons
+
+
+def pairwise_decoder_forward(codes_MB, ivf_codes, codebook_MKD, combine_mvals_m, K_base, ivf_code_map=None) -> np.ndarray:
+    """PairwiseDecoderIVF.map_codes (:126-130) + forward (:88-93)."""
+    codes_MB = np.asarray(codes_MB)
+    if ivf_code_map is not None:
+        assert ivf_codes.ndim == 1
+        codes_MB = np.concatenate([codes_MB, ivf_code_map[ivf_codes].T])
+    comb = codes_MB[combine_mvals_m[0]] * K_base + codes_MB[combine_mvals_m[1]]
+    xhat = codebook_MKD[0][comb[0]].astype(F32).copy()
+    for cb, c in zip(codebook_MKD[1:], comb[1:]):
+        xhat += cb[c]
+    return xhat

@@ -17,6 +17,7 @@ API_SYMBOLS = [
     "qinco_create", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
     "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
+    "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
 ]
 
 
@@ -96,6 +97,13 @@ def load() -> C.CDLL:
     lib.qinco_flops_per_vector_decode.argtypes = [vp]
     lib.qinco_flops_per_vector_decode.restype = dbl
     lib.qinco_shape_supported.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    I32P = C.POINTER(C.c_int32)
+    lib.qinco_lut_create.argtypes = [FP, C.c_int32, i64, C.c_int32, I32P, I32P, i64, C.POINTER(vp)]
+    lib.qinco_lut_destroy.argtypes = [vp]
+    lib.qinco_lut_decode.argtypes = [vp, vp, i32, C.c_int32, i64, vp, vp]
+    lib.qinco_lut_decode_host.argtypes = [vp, vp, i32, C.c_int32, i64, vp]
+    for name in ("qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host"):
+        getattr(lib, name).restype = C.c_int
     lib.qinco_last_error.restype = C.c_char_p
     lib.qinco_version.restype = C.c_char_p
     for name in ("qinco_create", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode",

@@ -14,6 +14,7 @@
 #include "../../include/qinco_hip.h"
 #include "aux_kernels.hpp"
 #include "ivf_kernel.hpp"
+#include "lut_kernel.hpp"
 #include "mlp_args.hpp"
 #include "mlp_launch.hpp"
 
@@ -910,6 +911,102 @@ extern "C" double qinco_flops_per_vector_encode(qinco_handle h) {
 extern "C" double qinco_flops_per_vector_decode(qinco_handle h) {
   if (!h) return 0.0;
   return (double)(h->d.M - 1) * mlp_flops_per_row(h->d);
+}
+
+// ---------------------------------------------------------------------------------------------
+// look-up decoders (f4)
+// ---------------------------------------------------------------------------------------------
+struct qinco_lut_s {
+  int device = 0;
+  LutArgs a{};
+  float* tables = nullptr;
+  int* err_flag = nullptr;
+  void* stage_codes = nullptr;
+  size_t stage_codes_bytes = 0;
+  float* stage_out = nullptr;
+  size_t stage_out_bytes = 0;
+};
+
+extern "C" int qinco_lut_create(const float* tables, int32_t J, int64_t Kt, int32_t D, const int32_t* a, const int32_t* b,
+                                int64_t mul, qinco_lut* out) {
+  if (!tables || !a || !out) return fail(QINCO_ERR_INVALID, "qinco_lut_create: null argument");
+  if (J < 1 || J > kLutMaxJ || Kt < 1 || D < 4 || D % 4 || mul < 1)
+    return fail(QINCO_ERR_INVALID, "qinco_lut_create: need 1 <= J <= %d, Kt >= 1, D %% 4 == 0, mul >= 1", kLutMaxJ);
+  qinco_lut_s* l = new qinco_lut_s();
+  auto bail = [&](int code) {
+    qinco_lut_destroy(l);
+    return code;
+  };
+  if (hipGetDevice(&l->device) != hipSuccess) return bail(fail(QINCO_ERR_HIP, "hipGetDevice failed (no HIP device?)"));
+  const size_t bytes = (size_t)J * Kt * D * sizeof(float);
+  if (hipMalloc((void**)&l->tables, bytes) != hipSuccess) return bail(fail(QINCO_ERR_HIP, "hipMalloc(%zu) failed", bytes));
+  if (hipMemcpy(l->tables, tables, bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(QINCO_ERR_HIP, "hipMemcpy failed"));
+  if (hipMalloc((void**)&l->err_flag, sizeof(int)) != hipSuccess || hipMemset(l->err_flag, 0, sizeof(int)) != hipSuccess)
+    return bail(fail(QINCO_ERR_HIP, "hipMalloc failed"));
+  l->a.tables = l->tables;
+  l->a.J = J;
+  l->a.D = D;
+  l->a.Kt = Kt;
+  l->a.mul = mul;
+  l->a.err_flag = l->err_flag;
+  for (int j = 0; j < J; ++j) {
+    l->a.a[j] = a[j];
+    l->a.b[j] = b ? b[j] : -1;
+    if (a[j] < 0) return bail(fail(QINCO_ERR_INVALID, "qinco_lut_create: a[%d] < 0", j));
+  }
+  *out = l;
+  return QINCO_OK;
+}
+
+extern "C" int qinco_lut_destroy(qinco_lut l) {
+  if (!l) return QINCO_OK;
+  (void)hipDeviceSynchronize();
+  if (l->tables) (void)hipFree(l->tables);
+  if (l->err_flag) (void)hipFree(l->err_flag);
+  if (l->stage_codes) (void)hipFree(l->stage_codes);
+  if (l->stage_out) (void)hipFree(l->stage_out);
+  delete l;
+  return QINCO_OK;
+}
+
+extern "C" int qinco_lut_decode(qinco_lut l, const void* codes, int code_dtype, int32_t Mc, int64_t n, float* out, void* stream) {
+  if (!l) return fail(QINCO_ERR_INVALID, "qinco_lut_decode: null handle");
+  if (n < 0 || code_dtype < 0 || code_dtype > 2 || Mc < 1) return fail(QINCO_ERR_INVALID, "qinco_lut_decode: bad argument");
+  if (n == 0) return QINCO_OK;
+  if (!codes || !out) return fail(QINCO_ERR_INVALID, "qinco_lut_decode: null buffer");
+  for (int j = 0; j < l->a.J; ++j)
+    if (l->a.a[j] >= Mc || l->a.b[j] >= Mc) return fail(QINCO_ERR_INVALID, "qinco_lut_decode: code column out of range (Mc=%d)", Mc);
+  HIP_TRY(hipSetDevice(l->device));
+  LutArgs a = l->a;
+  a.codes = codes;
+  a.code_dtype = code_dtype;
+  a.Mc = Mc;
+  a.n = n;
+  a.out = out;
+  hipLaunchKernelGGL(lut_decode_kernel, dim3(ew_grid(n * (a.D / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  HIP_TRY(hipGetLastError());
+  return QINCO_OK;
+}
+
+extern "C" int qinco_lut_decode_host(qinco_lut l, const void* codes, int code_dtype, int32_t Mc, int64_t n, float* out) {
+  if (!l) return fail(QINCO_ERR_INVALID, "qinco_lut_decode_host: null handle");
+  if (n == 0) return QINCO_OK;
+  if (!codes || !out || code_dtype < 0 || code_dtype > 2 || Mc < 1) return fail(QINCO_ERR_INVALID, "qinco_lut_decode_host: bad argument");
+  HIP_TRY(hipSetDevice(l->device));
+  const size_t cb = (size_t)n * Mc * code_size(code_dtype), ob = (size_t)n * l->a.D * 4;
+  int rc;
+  if ((rc = ensure_stage(&l->stage_codes, &l->stage_codes_bytes, cb))) return rc;
+  if ((rc = ensure_stage((void**)&l->stage_out, &l->stage_out_bytes, ob))) return rc;
+  HIP_TRY(hipMemcpy(l->stage_codes, codes, cb, hipMemcpyHostToDevice));
+  if ((rc = qinco_lut_decode(l, l->stage_codes, code_dtype, Mc, n, l->stage_out, nullptr))) return rc;
+  HIP_TRY(hipMemcpy(out, l->stage_out, ob, hipMemcpyDeviceToHost));
+  int flag = 0;
+  HIP_TRY(hipMemcpy(&flag, l->err_flag, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) {
+    HIP_TRY(hipMemset(l->err_flag, 0, sizeof(int)));
+    return fail(QINCO_ERR_RANGE, "qinco_lut_decode: a look-up index is outside its table");
+  }
+  return QINCO_OK;
 }
 
 extern "C" const char* qinco_last_error(void) { return g_last_error.c_str(); }

@@ -73,5 +73,34 @@ def main():
         eng.close()
 
 
+def lut_bandwidth():
+    """f4: HBM-side rate of the look-up decoders (bytes = codes in + J gathered rows + row out, per vector)."""
+    import torch
+    from qinco_amd.lut import LutDecoder
+    rs = np.random.RandomState(0)
+    dev = torch.device("cuda", 0)
+    for name, J, Kt, D, mul, n in (("AQ 8x256 d128", 8, 256, 128, 1, 1 << 22), ("pairwise 16x65536 d128", 16, 65536, 128, 256, 1 << 21)):
+        tab = rs.randn(J, Kt, D).astype(np.float32)
+        if mul == 1:
+            dec, Mc = LutDecoder(tab, a=np.arange(J)), J
+        else:
+            dec, Mc = LutDecoder(tab, a=rs.randint(0, 13, J), b=rs.randint(0, 13, J), mul=mul), 13
+        codes = torch.from_numpy(rs.randint(0, 256, (n, Mc)).astype(np.uint8)).to(dev)
+        dec(codes)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dec(codes)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        byts = n * (Mc + J * D * 4 + D * 4)
+        print(json.dumps({"workload": "lut_decode " + name, "vectors_per_s": n / dt, "GB_per_s": byts / dt / 1e9,
+                          "bytes_per_vector": byts / n}), flush=True)
+        dec.close()
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "lut":
+        lut_bandwidth()
+    else:
+        main()

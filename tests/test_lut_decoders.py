@@ -1,0 +1,41 @@
+"""look-up decoders (HBM-bound gather-add) against the oracle restatement -- bit-exact (fp32 adds in the
+reference's order).  Parity is UNPINNED for this row: the reference modules need faiss / torcheval to import."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reconstruct_from_fixed_codebooks_bit_exact():
+    from oracle.qinco_oracle import reconstruct_from_fixed_codebooks as ref
+    from qinco_amd.lut import reconstruct_from_fixed_codebooks
+    rs = np.random.RandomState(0)
+    for (n, M, K, D, dt) in [(1000, 8, 256, 128, np.uint8), (257, 16, 256, 96, np.int64), (1, 4, 64, 32, np.int32),
+                             (5000, 9, 256, 768, np.int64)]:
+        cb = rs.randn(M, K, D).astype(np.float32)
+        codes = rs.randint(0, K, (n, M)).astype(dt)
+        got = reconstruct_from_fixed_codebooks(codes, cb)
+        assert got.dtype == np.float32 and np.array_equal(got, ref(codes.astype(np.int64), cb))
+    assert reconstruct_from_fixed_codebooks(np.zeros((0, 4), np.int64), rs.randn(4, 8, 16).astype(np.float32)).shape == (0, 16)
+    with pytest.raises(IndexError):
+        reconstruct_from_fixed_codebooks(np.full((3, 4), 8, np.int64), rs.randn(4, 8, 16).astype(np.float32))
+
+
+def test_pairwise_decoder_bit_exact_and_device_path():
+    import torch
+    from oracle.qinco_oracle import pairwise_decoder_forward as ref
+    from qinco_amd.lut import PairwiseDecoder
+    rs = np.random.RandomState(1)
+    M, K, D, IVF_M, ivf_K, Mt, n = 8, 32, 128, 5, 200, 11, 3000
+    cb = rs.randn(Mt, K * K, D).astype(np.float32)
+    comb = rs.randint(0, M + IVF_M, (2, Mt))
+    imap = rs.randint(0, K, (ivf_K, IVF_M))
+    codes_MB = rs.randint(0, K, (M, n))
+    ivf = rs.randint(0, ivf_K, n)
+    dec = PairwiseDecoder(cb, comb, K, imap)
+    want = ref(codes_MB, ivf, cb, comb, K, imap)
+    got = dec(codes_MB, ivf)
+    assert np.array_equal(got, want)
+    cols = torch.from_numpy(dec.gather_codes(codes_MB, ivf)).cuda()
+    assert np.array_equal(dec._dec(cols).cpu().numpy(), want)
+    dec.close()

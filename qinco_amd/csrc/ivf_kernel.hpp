@@ -52,7 +52,15 @@ ivf_assign_kernel(const f32x4* __restrict__ cstream, const float* __restrict__ c
   const int cb0 = blockIdx.y * blocks_per_slice;
   int cb1 = cb0 + blocks_per_slice;
   if (cb1 > nblocks) cb1 = nblocks;
-  const f32x4* wp = cstream + (long)cb0 * (NDB * 4 * 64) + lane;
+  // The slice's fragments are one sequential stream; a P-deep register ring keeps P fragments in flight across the
+  // block boundary (without it every wave stalled on its 16 loads at the top of each block: 36 % of wave time in
+  // s_waitcnt, matrix pipe 62 % busy).  The host pads the stream by P fragments.
+  constexpr int NF = NDB * 4;                      // fragments per block of 32 centroids
+  constexpr int P = (NF % 16 == 0) ? 16 : NF;      // ring depth (divides NF so ring slots are compile-time)
+  const f32x4* wp = cstream + (long)cb0 * (NF * 64) + lane;
+  f32x4 ring[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
   float bestd = __builtin_inff();
   int besti = 0x7fffffff;
   for (int cb = cb0; cb < cb1; ++cb) {
@@ -63,13 +71,15 @@ ivf_assign_kernel(const f32x4* __restrict__ cstream, const float* __restrict__ c
     for (int ib = 0; ib < NDB; ++ib) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 w = wp[(ib * 4 + q) * 64];
+        const int i = ib * 4 + q;
+        const f32x4 w = ring[i % P];
+        ring[i % P] = wp[(i + P) * 64];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], xt[ib][4 * q + e], acc, 0, 0, 0);
       }
     }
-    wp += NDB * 4 * 64;
+    wp += NF * 64;
     // lane holds centroids cb*32 + 8g + 4*half + e  (g = r>>2, e = r&3) of its vector
 #pragma unroll
     for (int g = 0; g < 4; ++g) {

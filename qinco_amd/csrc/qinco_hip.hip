@@ -224,6 +224,7 @@ static int upload_fragments(qinco_handle_s* h, const float* cb, int K, int D, f3
   for (int kb = 0; kb < K / 32; ++kb)
     for (int ib = 0; ib < D / 32; ++ib)
       for (int q = 0; q < 4; ++q) put_frag(s, cb, D, kb, ib, q);
+  s.resize(s.size() + (size_t)16 * 256, 0.f);  // the table kernels prefetch up to 16 fragments past the end
   float* ds = nullptr;
   int rc = upload(h, &ds, s.data(), s.size());
   *out = reinterpret_cast<f32x4*>(ds);

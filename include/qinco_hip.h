@@ -131,6 +131,26 @@ QINCO_API int qinco_lut_decode(qinco_lut lut, const void* codes, int code_dtype,
 /* host buffers; synchronous; QINCO_ERR_RANGE if a look-up index falls outside its table. */
 QINCO_API int qinco_lut_decode_host(qinco_lut lut, const void* codes, int code_dtype, int32_t Mc, int64_t n, float* out);
 
+/* ---- evaluation stages either side of the hot path -----------------------------------------
+ * Brute-force L2 top-k of run_search_full_direct_small_db (qinco/search/search_tasks.py:551-603):
+ *   ids[q] = argsort_n( |queries[q]|^2 + |db[n]|^2 - 2 queries[q].db[n] )[:k]     (approx_pairwise_distance,
+ *   qinco/utils.py:336-346, fp32; ties -> lower n, i.e. a stable argsort), dist = the matching distances ascending.
+ * D in {32, 64, 96, 128, 256, 768}; 1 <= k <= min(n, 2048); n <= 2^31.  Scratch (a distance table of up to 8 GiB
+ * per chunk of queries) is owned by the handle and grows on demand. */
+typedef struct qinco_knn_s* qinco_knn;
+QINCO_API int qinco_knn_create(int32_t D, qinco_knn* out);
+QINCO_API int qinco_knn_destroy(qinco_knn knn);
+/* db (n, D), queries (nq, D) fp32 row-major on the device; ids_out (nq, k) int64, dist_out (nq, k) fp32 or NULL on the
+ * device; enqueued on `stream`, not synchronised. */
+QINCO_API int qinco_knn_search(qinco_knn knn, const float* db, int64_t n, const float* queries, int64_t nq, int32_t k,
+                               int64_t* ids_out, float* dist_out, void* stream);
+/* the same on host buffers; synchronous */
+QINCO_API int qinco_knn_search_host(qinco_knn knn, const float* db, int64_t n, const float* queries, int64_t nq, int32_t k,
+                                    int64_t* ids_out, float* dist_out);
+/* *sum_out = sum_i (a[i] - b[i])^2 over `count` floats on the device (AnyVectMSE.update, qinco/metrics.py:43-50;
+ * accumulated in fp64); synchronises `stream`. */
+QINCO_API int qinco_sqerr_sum(const float* a, const float* b, int64_t count, double* sum_out, void* stream);
+
 QINCO_API const char* qinco_last_error(void);
 QINCO_API const char* qinco_version(void);
 

@@ -236,3 +236,26 @@ def pairwise_decoder_forward(codes_MB, ivf_codes, codebook_MKD, combine_mvals_m,
     for cb, c in zip(codebook_MKD[1:], comb[1:]):
         xhat += cb[c]
     return xhat
+
+
+# --------------------------------------------------------------------------------------------------
+# f3: small-db search.  run_search_full_direct_small_db (qinco/search/search_tasks.py:551-603) and
+# compute_recalls (:275-282).  search_tasks.py needs faiss to import; the golden tests/golden/search_small_db.npz was
+# produced by driving these lines with the reference's own model and approx_pairwise_distance (make_golden.py).
+# --------------------------------------------------------------------------------------------------
+def small_db_shortlists(xhat_db: np.ndarray, queries: np.ndarray, nshort: int = 100, bs: int = 100):
+    """search_tasks.py:585-597: per query batch, approx_pairwise_distance to all reconstructions, argsort, first
+    `nshort`.  Returns (ids (Q, nshort) int64, the matching distances)."""
+    ids, dd = [], []
+    for i0 in range(0, len(queries), bs):
+        d = approx_pairwise_distance(queries[i0:i0 + bs].astype(F32), xhat_db.astype(F32))
+        order = np.argsort(d, axis=-1, kind="stable")[:, :nshort]
+        ids.append(order)
+        dd.append(np.take_along_axis(d, order, axis=-1))
+    return np.concatenate(ids).astype(np.int64), np.concatenate(dd).astype(F32)
+
+
+def compute_recalls(I: np.ndarray, gt: np.ndarray) -> dict:
+    """search_tasks.py:275-282."""
+    assert I.ndim == 2 and gt.ndim == 2
+    return {rank: float((I[:, :rank] == gt[:, :1]).sum() / gt.shape[0]) for rank in (1, 10, 100)}

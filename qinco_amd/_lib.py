@@ -18,6 +18,7 @@ API_SYMBOLS = [
     "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
     "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
+    "qinco_knn_create", "qinco_knn_destroy", "qinco_knn_search", "qinco_knn_search_host", "qinco_sqerr_sum",
 ]
 
 
@@ -102,6 +103,11 @@ def load() -> C.CDLL:
     lib.qinco_lut_destroy.argtypes = [vp]
     lib.qinco_lut_decode.argtypes = [vp, vp, i32, C.c_int32, i64, vp, vp]
     lib.qinco_lut_decode_host.argtypes = [vp, vp, i32, C.c_int32, i64, vp]
+    lib.qinco_knn_create.argtypes = [C.c_int32, C.POINTER(vp)]
+    lib.qinco_knn_destroy.argtypes = [vp]
+    lib.qinco_knn_search.argtypes = [vp, vp, i64, vp, i64, C.c_int32, vp, vp, vp]
+    lib.qinco_knn_search_host.argtypes = [vp, vp, i64, vp, i64, C.c_int32, vp, vp]
+    lib.qinco_sqerr_sum.argtypes = [vp, vp, i64, C.POINTER(dbl), vp]
     for name in ("qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host"):
         getattr(lib, name).restype = C.c_int
     lib.qinco_last_error.restype = C.c_char_p

@@ -66,6 +66,11 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     objs.append(o)
     if force or not _newer(o, headers + [CSRC / "qinco_hip.hip"]):
         tasks.append((o, [cc, *FLAGS, "-c", str(CSRC / "qinco_hip.hip"), "-o", str(o)]))
+    o = OBJ / "search_hip.o"
+    objs.append(o)
+    if force or not _newer(o, [CSRC / n for n in ("search_hip.hip", "knn_kernel.hpp", "abi_util.hpp", "mlp_args.hpp")]
+                           + [PKG.parent / "include" / "qinco_hip.h"]):
+        tasks.append((o, [cc, *FLAGS, "-c", str(CSRC / "search_hip.hip"), "-o", str(o)]))
     if tasks:
         if verbose:
             print(f"[qinco_amd.build] compiling {len(tasks)} object(s) for {ARCH}", file=sys.stderr)

@@ -1,0 +1,277 @@
+// Brute-force L2 top-k of the small-db search that follows the hot path:
+//   run_search_full_direct_small_db (reference qinco/search/search_tasks.py:551-603):
+//     dists = approx_pairwise_distance(queries, xhat_db)  (utils.py:336-346:  |q|^2 + |x|^2 - 2 q.x, fp32)
+//     shortlist = dists.argsort(-1)[:, :100]
+// Two kernels per chunk of queries:
+//   knn_table_kernel<D>  the (queries x db) distance table on the fp32 MFMA with the transposed trick of the IVF
+//                        kernel, roles swapped: a wave keeps 32 DATABASE rows as B operands in registers and
+//                        streams the chunk's query fragments (packed on the device, L2-resident) as A operands, so
+//                        the 32x32 result tile leaves lanes 0..31 with 32 consecutive database columns of one query
+//                        row: 128-byte contiguous stores into table[query][db].  The database is read once per chunk.
+//                        2 D FLOP per pair; 4 B written per pair.  MFMA-bound (D=128: 4 KiB stored per 4096 pipe cycles
+//                        per SIMD = 2.4 TB/s of HBM writes chip-wide).
+//   knn_select_kernel    one workgroup per query row: radix select of the k smallest 64-bit keys
+//                        (order-preserving distance bits, db index) -- 12-bit LDS histograms refine a key prefix
+//                        until the k-th key's bucket and everything below it fit an LDS buffer, one compaction pass
+//                        collects them, a bitonic sort orders them.  Ties resolve to the lower index (stable argsort).
+//                        HBM-bound: the row is read 2 (rarely 3+) times: 8-12 B per pair.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mlp_args.hpp"
+
+namespace qinco {
+
+// rows (n, D) row-major -> fragment stream of ceil(n/32) blocks (same layout as put_frag in qinco_hip.hip:
+// fragment (block, ib, q): lane l, component e = rows[block*32 + (l&31)][ib*32 + 8q + 4(l>>5) + e]); rows >= n are 0.
+// norms[r] = sum_d rows[r][d]^2 (sequential fp32), 0 for padding rows.
+__global__ void __launch_bounds__(256)
+knn_pack_rows_kernel(const float* __restrict__ rows, long n, int D, f32x4* __restrict__ stream, float* __restrict__ norms,
+                     long nblocks) {
+  const int NDB = D / 32;
+  const long total = nblocks * NDB * 4 * 64;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(t & 63);
+    const long frag = t >> 6;
+    const int q = (int)(frag & 3);
+    const long bi = frag >> 2;
+    const int ib = (int)(bi % NDB);
+    const long blk = bi / NDB;
+    const long r = blk * 32 + (l & 31);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < n) v = *reinterpret_cast<const f32x4*>(rows + r * D + ib * 32 + 8 * q + 4 * (l >> 5));
+    stream[t] = v;
+  }
+  const long nrows = nblocks * 32;
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    if (r < n)
+      for (int d = 0; d < D; ++d) s = fmaf(rows[r * D + d], rows[r * D + d], s);
+    norms[r] = s;
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256)
+knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qnorm, int nqblocks,
+                 const float* __restrict__ db, long N, float* __restrict__ table, long ldt) {
+  constexpr int NDB = D / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, half = lane >> 5;
+  const long n0 = ((long)blockIdx.x * 4 + wave) * 32;
+  if (n0 >= N) return;
+  long row = n0 + j;
+  const bool valid = row < N;
+  if (!valid) row = N - 1;
+  const float* xp = db + row * D + half * 4;
+  f32x16 xt[NDB];
+  float xn = 0.f;
+#pragma unroll
+  for (int ib = 0; ib < NDB; ++ib) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(xp + ib * 32 + 8 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xt[ib][4 * q + e] = t[e];
+        xn = fmaf(t[e], t[e], xn);
+      }
+    }
+  }
+  xn += __shfl_xor(xn, 32);
+
+  constexpr int NF = NDB * 4;
+  constexpr int P = (NF % 16 == 0) ? 16 : NF;  // register ring, as in ivf_assign_kernel (stream padded by P)
+  const f32x4* wp = qstream + lane;
+  f32x4 ring[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
+  float* tp = table + n0 + j;
+  for (int qb = 0; qb < nqblocks; ++qb) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int ib = 0; ib < NDB; ++ib) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = ib * 4 + q;
+        const f32x4 w = ring[i % P];
+        ring[i % P] = wp[(i + P) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], xt[ib][4 * q + e], acc, 0, 0, 0);
+      }
+    }
+    wp += NF * 64;
+    // lane holds queries qb*32 + 8g + 4*half + e of database row n0 + j
+    if (valid) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int base = qb * 32 + 8 * g + 4 * half;
+        const f32x4 qn = *reinterpret_cast<const f32x4*>(qnorm + base);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          tp[(long)(base + e) * ldt] = __fsub_rn(__fadd_rn(qn[e], xn), __fmul_rn(2.f, acc[4 * g + e]));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// selection
+// ---------------------------------------------------------------------------------------------
+constexpr int kKnnCap = 8192;      // LDS candidate buffer (64 KiB of 64-bit keys)
+constexpr int kKnnThreads = 1024;
+constexpr int kKnnMaxK = 2048;
+
+__device__ __forceinline__ unsigned long long knn_key(float d, unsigned idx) {
+  unsigned u = __builtin_bit_cast(unsigned, d);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> unsigned (NaNs sort last)
+  return ((unsigned long long)u << 32) | idx;
+}
+__device__ __forceinline__ float knn_key_dist(unsigned long long key) {
+  unsigned u = (unsigned)(key >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __builtin_bit_cast(float, u);
+}
+
+// table: (nq, ldt) fp32, row q holds N distances.  ids_out (nq, k) int64, dist_out (nq, k) fp32 or nullptr.
+__global__ void __launch_bounds__(kKnnThreads)
+knn_select_kernel(const float* __restrict__ table, long ldt, long N, int k, long long* __restrict__ ids_out,
+                  float* __restrict__ dist_out) {
+  __shared__ unsigned hist[4096];
+  __shared__ unsigned long long buf[kKnnCap];
+  __shared__ unsigned s_ub, s_bucket, s_before, s_cnt, s_count;
+  const int tid = threadIdx.x;
+  const float* row = table + (long)blockIdx.x * ldt;
+
+  unsigned long long prefix = 0;  // the k-th key starts with these `pbits` bits
+  int pbits = 0;
+  unsigned long long below = 0;   // keys strictly below the prefix range
+  // histogram of the next digit over keys matching the prefix; bins above a running bound are not needed
+  // (the bound only shrinks), which removes almost all LDS atomics after the first segment
+  while (true) {
+    const int w = (64 - pbits) < 12 ? (64 - pbits) : 12;
+    const int shift = 64 - pbits - w;
+    for (int i = tid; i < 4096; i += kKnnThreads) hist[i] = 0;
+    if (tid == 0) s_ub = 4095;
+    __syncthreads();
+    const unsigned need = (unsigned)(k - below);  // rank of the k-th key inside the prefix range (>= 1)
+    constexpr long SEG = (long)kKnnThreads * 16;  // multiple of 4 * kKnnThreads
+    int seg_i = 0;
+    for (long s0 = 0; s0 < N; s0 += SEG, ++seg_i) {
+      const unsigned ub = s_ub;
+      const long s1 = (s0 + SEG < N) ? s0 + SEG : N;
+      for (long i = s0 + 4 * tid; i < s1; i += 4 * kKnnThreads) {  // rows are 128-byte aligned (ldt % 32 == 0)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned long long key = knn_key(v[e], (unsigned)(i + e));
+          if (i + e < N && (pbits == 0 || (key >> (64 - pbits)) == prefix)) {
+            const unsigned dgt = (unsigned)(key >> shift) & ((1u << w) - 1u);
+            if (dgt <= ub) atomicAdd(&hist[dgt], 1u);
+          }
+        }
+      }
+      __syncthreads();
+      const bool last = s1 >= N;
+      if (last || (seg_i & (seg_i + 1)) == 0) {  // after segments 1, 2, 4, 8, ... and at the end
+        if (tid < 64) {
+          // wave 0: lane l owns bins [64 l, 64 l + 64); find the first bin where the running count reaches `need`
+          unsigned sum = 0;
+          for (int b = 0; b < 64; ++b) sum += hist[tid * 64 + b];
+          unsigned incl = sum;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(incl, off);
+            if (tid >= off) incl += o;
+          }
+          const unsigned excl = incl - sum;
+          const bool mine = excl < need && incl >= need;
+          if (mine) {
+            unsigned run = excl;
+            for (int b = 0; b < 64; ++b) {
+              const unsigned c = hist[tid * 64 + b];
+              if (run + c >= need) {
+                s_bucket = tid * 64 + b;
+                s_before = run;
+                s_cnt = c;
+                s_ub = tid * 64 + b;
+                break;
+              }
+              run += c;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    const unsigned bucket = s_bucket, before = s_before, cnt = s_cnt;
+    __syncthreads();
+    below += before;
+    prefix = (prefix << w) | bucket;
+    pbits += w;
+    if (below + cnt <= (unsigned long long)kKnnCap || pbits >= 64) break;
+  }
+
+  // collect every key whose leading pbits are <= prefix (>= k of them, <= kKnnCap)
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+  for (long i = 4 * tid; i < N; i += 4 * kKnnThreads) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned long long key = knn_key(v[e], (unsigned)(i + e));
+      if (i + e < N && (key >> (64 - pbits)) <= prefix) {
+        const unsigned pos = atomicAdd(&s_count, 1u);
+        if (pos < (unsigned)kKnnCap) buf[pos] = key;
+      }
+    }
+  }
+  __syncthreads();
+  const int count = (int)s_count;
+  int n2 = 64;
+  while (n2 < count) n2 <<= 1;
+  for (int i = count + tid; i < n2; i += kKnnThreads) buf[i] = ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < n2 / 2; t += kKnnThreads) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = buf[lo], b = buf[hi];
+        if ((a > b) == up) {
+          buf[lo] = b;
+          buf[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < k; i += kKnnThreads) {
+    const unsigned long long key = buf[i];
+    ids_out[(long)blockIdx.x * k + i] = (long long)(key & 0xffffffffull);
+    if (dist_out) dist_out[(long)blockIdx.x * k + i] = knn_key_dist(key);
+  }
+}
+
+// sum over count elements of (a - b)^2, fp64 accumulation (AnyVectMSE.update, reference qinco/metrics.py:43-50)
+__global__ void __launch_bounds__(256)
+sqerr_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, long count, double* __restrict__ out) {
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    s += (double)d * (double)d;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+}  // namespace qinco

@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/qinco_hip.h"
+#include "abi_util.hpp"
 #include "aux_kernels.hpp"
 #include "ivf_kernel.hpp"
 #include "lut_kernel.hpp"
@@ -53,7 +53,7 @@ const MlpInstance* find_mlp_instance(int D, int De, int Dh, int want_P, int want
 // ---------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 
-static int fail(int code, const char* fmt, ...) {
+int qinco::abi_fail(int code, const char* fmt, ...) {
   char buf[1024];
   va_list ap;
   va_start(ap, fmt);
@@ -62,13 +62,7 @@ static int fail(int code, const char* fmt, ...) {
   g_last_error = buf;
   return code;
 }
-
-#define HIP_TRY(expr)                                                                         \
-  do {                                                                                        \
-    hipError_t _e = (expr);                                                                   \
-    if (_e != hipSuccess)                                                                     \
-      return fail(QINCO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-  } while (0)
+#define fail qinco::abi_fail
 
 // ---------------------------------------------------------------------------------------------
 // handle

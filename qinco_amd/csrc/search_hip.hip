@@ -1,0 +1,178 @@
+// C ABI of the evaluation stages either side of the hot path (include/qinco_hip.h): brute-force top-k of the
+// small-db search (run_search_full_direct_small_db, reference qinco/search/search_tasks.py:551-603) and the
+// squared-error sum of compute_MSE / AnyVectMSE (qinco/qinco_tasks.py:87-148, qinco/metrics.py:29-58).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "abi_util.hpp"
+#include "knn_kernel.hpp"
+
+using namespace qinco;
+#define fail qinco::abi_fail
+
+struct qinco_knn_s {
+  int device = 0;
+  int D = 0;
+  f32x4* qstream = nullptr;  // packed query fragments of one chunk (+16 fragments of padding)
+  float* qnorm = nullptr;
+  size_t q_rows = 0;         // chunk capacity in query rows (multiple of 32)
+  float* table = nullptr;
+  size_t table_elems = 0;
+  // staging for the host form
+  void* s_db = nullptr;
+  size_t s_db_bytes = 0;
+  void* s_q = nullptr;
+  size_t s_q_bytes = 0;
+  void* s_ids = nullptr;
+  size_t s_ids_bytes = 0;
+  void* s_dist = nullptr;
+  size_t s_dist_bytes = 0;
+};
+
+static int grow(void** p, size_t* cap, size_t need) {
+  if (*cap >= need) return 0;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  HIP_TRY(hipMalloc(p, need ? need : 16));
+  *cap = need;
+  return 0;
+}
+
+static bool knn_dim_ok(int D) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 256 || D == 768; }
+
+extern "C" int qinco_knn_create(int32_t D, qinco_knn* out) {
+  if (!out) return fail(QINCO_ERR_INVALID, "qinco_knn_create: null argument");
+  if (!knn_dim_ok(D)) return fail(QINCO_ERR_UNSUPPORTED, "qinco_knn_create: no table kernel instance for D=%d", D);
+  qinco_knn_s* s = new qinco_knn_s();
+  s->D = D;
+  if (hipGetDevice(&s->device) != hipSuccess) {
+    delete s;
+    return fail(QINCO_ERR_HIP, "hipGetDevice failed (no HIP device?)");
+  }
+  *out = s;
+  return QINCO_OK;
+}
+
+extern "C" int qinco_knn_destroy(qinco_knn s) {
+  if (!s) return QINCO_OK;
+  (void)hipDeviceSynchronize();
+  for (void* p : {(void*)s->qstream, (void*)s->qnorm, (void*)s->table, s->s_db, s->s_q, s->s_ids, s->s_dist})
+    if (p) (void)hipFree(p);
+  delete s;
+  return QINCO_OK;
+}
+
+template <int D>
+static void launch_table(qinco_knn_s* s, int nqblocks, const float* db, long n, long ldt, hipStream_t st) {
+  hipLaunchKernelGGL(knn_table_kernel<D>, dim3((unsigned)((n + 127) / 128)), dim3(256), 0, st, s->qstream, s->qnorm, nqblocks, db,
+                     n, s->table, ldt);
+}
+
+extern "C" int qinco_knn_search(qinco_knn s, const float* db, int64_t n, const float* queries, int64_t nq, int32_t k,
+                                int64_t* ids_out, float* dist_out, void* stream) {
+  if (!s) return fail(QINCO_ERR_INVALID, "qinco_knn_search: null handle");
+  if (n < 1 || n > (int64_t)1 << 31 || nq < 0 || k < 1 || k > kKnnMaxK || k > n)
+    return fail(QINCO_ERR_INVALID, "qinco_knn_search: need 1 <= k <= min(n, %d), n <= 2^31 (n=%lld, k=%d)", kKnnMaxK, (long long)n, k);
+  if (nq == 0) return QINCO_OK;
+  if (!db || !queries || !ids_out) return fail(QINCO_ERR_INVALID, "qinco_knn_search: null buffer");
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int D = s->D;
+  const long ldt = (n + 31) / 32 * 32;
+  // chunk of queries: table of at most 8 GiB (the card has 288 GB; the database is re-read once per chunk)
+  long chunk = (long)(((size_t)8 << 30) / ((size_t)ldt * 4)) / 32 * 32;
+  if (chunk < 32) chunk = 32;
+  if (chunk > 4096) chunk = 4096;
+  // every wave loops over the whole query stream: keep it L2-resident (4 MiB per XCD), about 1 MiB
+  const long l2_rows = ((long)1 << 20) / (D * 4) / 32 * 32;
+  if (chunk > l2_rows) chunk = l2_rows;
+  const long nq_pad = (nq + 31) / 32 * 32;
+  if (chunk > nq_pad) chunk = nq_pad;
+  int rc;
+  if (s->q_rows < (size_t)chunk) {
+    size_t cap = 0;
+    if (s->qstream) (void)hipFree(s->qstream);
+    if (s->qnorm) (void)hipFree(s->qnorm);
+    s->qstream = nullptr;
+    s->qnorm = nullptr;
+    s->q_rows = 0;
+    if ((rc = grow((void**)&s->qstream, &cap, ((size_t)chunk * D + 16 * 256) * sizeof(float)))) return rc;
+    HIP_TRY(hipMemsetAsync(s->qstream, 0, ((size_t)chunk * D + 16 * 256) * sizeof(float), st));
+    cap = 0;
+    if ((rc = grow((void**)&s->qnorm, &cap, (size_t)chunk * sizeof(float)))) return rc;
+    s->q_rows = (size_t)chunk;
+  }
+  {
+    size_t bytes = s->table_elems * sizeof(float);
+    if ((rc = grow((void**)&s->table, &bytes, (size_t)chunk * ldt * sizeof(float)))) return rc;
+    s->table_elems = bytes / sizeof(float);
+  }
+  for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+    const long cq = (nq - q0 < chunk) ? (long)(nq - q0) : chunk;
+    const long nqb = (cq + 31) / 32;
+    long g = (nqb * 32 * (D / 4) + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(knn_pack_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, queries + q0 * D, cq, D, s->qstream, s->qnorm, nqb);
+    HIP_TRY(hipGetLastError());
+    switch (D) {
+      case 32: launch_table<32>(s, (int)nqb, db, n, ldt, st); break;
+      case 64: launch_table<64>(s, (int)nqb, db, n, ldt, st); break;
+      case 96: launch_table<96>(s, (int)nqb, db, n, ldt, st); break;
+      case 128: launch_table<128>(s, (int)nqb, db, n, ldt, st); break;
+      case 256: launch_table<256>(s, (int)nqb, db, n, ldt, st); break;
+      case 768: launch_table<768>(s, (int)nqb, db, n, ldt, st); break;
+      default: return fail(QINCO_ERR_UNSUPPORTED, "no table kernel instance for D=%d", D);
+    }
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)cq), dim3(kKnnThreads), 0, st, s->table, ldt, (long)n, (int)k,
+                       reinterpret_cast<long long*>(ids_out) + q0 * k, dist_out ? dist_out + q0 * k : nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  return QINCO_OK;
+}
+
+extern "C" int qinco_knn_search_host(qinco_knn s, const float* db, int64_t n, const float* queries, int64_t nq, int32_t k,
+                                     int64_t* ids_out, float* dist_out) {
+  if (!s) return fail(QINCO_ERR_INVALID, "qinco_knn_search_host: null handle");
+  if (nq == 0 && n >= 1 && k >= 1 && k <= n) return QINCO_OK;
+  if (!db || !queries || !ids_out || n < 1 || nq < 0 || k < 1) return fail(QINCO_ERR_INVALID, "qinco_knn_search_host: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  int rc;
+  const size_t dbb = (size_t)n * s->D * 4, qb = (size_t)nq * s->D * 4, ib = (size_t)nq * k * 8, fb = (size_t)nq * k * 4;
+  if ((rc = grow(&s->s_db, &s->s_db_bytes, dbb))) return rc;
+  if ((rc = grow(&s->s_q, &s->s_q_bytes, qb))) return rc;
+  if ((rc = grow(&s->s_ids, &s->s_ids_bytes, ib))) return rc;
+  if (dist_out && (rc = grow(&s->s_dist, &s->s_dist_bytes, fb))) return rc;
+  HIP_TRY(hipMemcpy(s->s_db, db, dbb, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->s_q, queries, qb, hipMemcpyHostToDevice));
+  if ((rc = qinco_knn_search(s, (const float*)s->s_db, n, (const float*)s->s_q, nq, k, (int64_t*)s->s_ids,
+                             dist_out ? (float*)s->s_dist : nullptr, nullptr)))
+    return rc;
+  HIP_TRY(hipMemcpy(ids_out, s->s_ids, ib, hipMemcpyDeviceToHost));
+  if (dist_out) HIP_TRY(hipMemcpy(dist_out, s->s_dist, fb, hipMemcpyDeviceToHost));
+  return QINCO_OK;
+}
+
+extern "C" int qinco_sqerr_sum(const float* a, const float* b, int64_t count, double* sum_out, void* stream) {
+  if (!sum_out || count < 0) return fail(QINCO_ERR_INVALID, "qinco_sqerr_sum: bad argument");
+  *sum_out = 0.0;
+  if (count == 0) return QINCO_OK;
+  if (!a || !b) return fail(QINCO_ERR_INVALID, "qinco_sqerr_sum: null buffer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  double* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, sizeof(double)));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(double), st);
+  if (e == hipSuccess) {
+    long g = (count + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(sqerr_sum_kernel, dim3((unsigned)g), dim3(256), 0, st, a, b, (long)count, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(sum_out, d, sizeof(double), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(QINCO_ERR_HIP, "qinco_sqerr_sum failed: %s", hipGetErrorString(e));
+  return QINCO_OK;
+}

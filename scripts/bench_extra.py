@@ -99,8 +99,33 @@ def lut_bandwidth():
         dec.close()
 
 
+def knn_rate():
+    """f3: brute-force top-100 at the reference's small-db scale (bigann1M: N = 1e6, Q = 1e4, D = 128) and D = 768."""
+    import torch
+    from qinco_amd.search import KnnSearcher
+    dev = torch.device("cuda", 0)
+    for D, N, Q in ((128, 1_000_000, 10_000), (768, 1_000_000, 2_048)):
+        g = torch.Generator(device=dev).manual_seed(0)
+        db = torch.randn(N, D, device=dev, generator=g)
+        q = torch.randn(Q, D, device=dev, generator=g)
+        knn = KnnSearcher(D)
+        knn.search(db, q, k=100)   # warm-up at the full shape (allocates the table scratch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ids = knn.search(db, q, k=100)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"workload": f"knn top-100 N={N} Q={Q} D={D}", "seconds": dt, "queries_per_s": Q / dt,
+                          "table_tflops": 2.0 * D * N * Q / dt / 1e12, "pairs_per_s": N * Q / dt}), flush=True)
+        assert ids.shape == (Q, 100)
+        knn.close()
+        del db, q
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "lut":
         lut_bandwidth()
+    elif len(sys.argv) > 1 and sys.argv[1] == "knn":
+        knn_rate()
     else:
         main()

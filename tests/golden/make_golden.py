@@ -161,8 +161,51 @@ def write_tiny_checkpoint():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def run_search_case() -> dict:
+    """Small-db search.  qinco/search/search_tasks.py needs faiss to import, so the harness lines of
+    run_search_full_direct_small_db (:551-603) are driven here step by step with the reference's own model and its own
+    approx_pairwise_distance (qinco/utils.py:336-346): encode + decode the database with the reference wrapper,
+    distances of query batches of 100 to the reconstructions, argsort, first 100 columns, recall of gt[:, 0]."""
+    from qinco.utils import approx_pairwise_distance
+    cfg, seed, _ = CASES["tiny_proj_beam"]
+    sd = synth_state_dict(cfg, seed)
+    model, wrapper = build_reference(cfg, sd)
+    N, Q, nshort = 3000, 150, 100
+    # clustered database so that near neighbours exist: vectors = decode(random codes) + noise; queries = db rows + noise
+    rs = np.random.RandomState(77)
+    with torch.no_grad():
+        base = model(torch.from_numpy(synth_codes(cfg, N, seed=78)), step="decode").numpy()
+    db = (base + 0.5 * float(sd["data_std"]) * rs.randn(N, cfg.D)).astype(np.float32)
+    qsrc = rs.choice(N, Q, replace=False)
+    queries = (db[qsrc] + 2.0 * float(sd["data_std"]) * rs.randn(Q, cfg.D)).astype(np.float32)
+    d_exact = ((queries[:, None, :].astype(np.float64) - db[None].astype(np.float64)) ** 2).sum(-1)
+    gt = np.argsort(d_exact, axis=1, kind="stable")[:, :100].astype(np.int64)
+    with torch.no_grad():
+        parts = []
+        for i0 in range(0, N, 1024):
+            b = torch.from_numpy(db[i0:i0 + 1024])
+            parts.append(wrapper(wrapper(b, step="encode"), step="decode"))
+        xhat = torch.concat(parts, dim=0)
+        qt = torch.from_numpy(queries)
+        sl, ds = [], []
+        for i0 in range(0, Q, 100):
+            d = approx_pairwise_distance(qt[i0:i0 + 100].unsqueeze(1), xhat).squeeze(1)
+            order = d.argsort(dim=-1)[:, :nshort]
+            sl.append(order)
+            ds.append(torch.sort(d, dim=-1).values[:, :nshort + 1])
+        shortlists = torch.concat(sl).numpy()
+        dsorted = torch.concat(ds).numpy()
+    recalls = [float((shortlists[:, :r] == gt[:, :1]).sum() / gt.shape[0]) for r in (1, 10, 100)]
+    gap = (dsorted[:, 1:] - dsorted[:, :-1]) / np.maximum(np.abs(dsorted[:, 1:]), 1e-12)
+    print(f"search_small_db          N={N} Q={Q} recalls {recalls}  min rel gap {gap.min():.2e}")
+    return {"db": db, "queries": queries, "gt": gt, "xhat": xhat.numpy(), "shortlists": shortlists.astype(np.int64),
+            "dist_sorted": dsorted.astype(np.float32), "recalls": np.asarray(recalls, np.float64)}
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    if not only or "search_small_db" in only:
+        np.savez_compressed(HERE / "search_small_db.npz", **run_search_case())
     for name, (cfg, seed, n) in CASES.items():
         if only and name not in only:
             continue

@@ -10,16 +10,72 @@ namespace qinco {
 
 #define QINCO_DEV __device__ __forceinline__
 
-// Lexicographic (value, index) minimum across the 64 lanes of a wave (ties -> lower index, which is
-// what argmin returns on the reference CPU path; topk's order among exact ties is unspecified).
+// Lexicographic (value, index) minimum across the 64 lanes of a wave, result in every lane (ties -> lower index,
+// which is what argmin returns on the reference CPU path; topk's order among exact ties is unspecified).
+// All on the VALU: DPP lane permutes inside the 16-lane rows, gfx950's v_permlane16_swap / v_permlane32_swap across
+// rows.  (__shfl_xor is ds_bpermute_b32: an LDS-crossbar round trip per level; the T-round selections were bound by
+// exactly that latency.)  Needs all 64 lanes active.
+template <int CTRL>
+QINCO_DEV float dpp_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+QINCO_DEV int dpp_i(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false);
+}
+QINCO_DEV void lexmin(float& v, int& i, float ov, int oi) {
+  const bool take = (ov < v) || (ov == v && oi < i);
+  v = take ? ov : v;
+  i = take ? oi : i;
+}
+QINCO_DEV void wave_argmin_lex(float& v, int& i) {
+  lexmin(v, i, dpp_f<0xB1>(v), dpp_i<0xB1>(i));    // quad_perm [1,0,3,2]: lane ^ 1
+  lexmin(v, i, dpp_f<0x4E>(v), dpp_i<0x4E>(i));    // quad_perm [2,3,0,1]: lane ^ 2
+  lexmin(v, i, dpp_f<0x141>(v), dpp_i<0x141>(i));  // row_half_mirror: pairs the two quads of each 8 lanes
+  lexmin(v, i, dpp_f<0x140>(v), dpp_i<0x140>(i));  // row_mirror: pairs the two halves of each row
+  {  // rows 0<->1 and 2<->3: after the swap one result holds the even row's value, the other the odd row's
+    const unsigned vb = __builtin_bit_cast(unsigned, v), ib = (unsigned)i;
+    const auto rv = __builtin_amdgcn_permlane16_swap(vb, vb, false, false);
+    const auto ri = __builtin_amdgcn_permlane16_swap(ib, ib, false, false);
+    v = __builtin_bit_cast(float, (unsigned)rv[0]);
+    i = (int)ri[0];
+    lexmin(v, i, __builtin_bit_cast(float, (unsigned)rv[1]), (int)ri[1]);
+  }
+  {  // lower 32 lanes <-> upper 32 lanes
+    const unsigned vb = __builtin_bit_cast(unsigned, v), ib = (unsigned)i;
+    const auto rv = __builtin_amdgcn_permlane32_swap(vb, vb, false, false);
+    const auto ri = __builtin_amdgcn_permlane32_swap(ib, ib, false, false);
+    v = __builtin_bit_cast(float, (unsigned)rv[0]);
+    i = (int)ri[0];
+    lexmin(v, i, __builtin_bit_cast(float, (unsigned)rv[1]), (int)ri[1]);
+  }
+}
+
+// The same result with a third of the instructions in the common case: reduce the VALUE alone (one v_min per level),
+// then look at which lanes hold it.  One lane: its index is the answer (v_readlane).  Several lanes (exact ties, rare):
+// fall back to the lexicographic reduction so that the lowest index wins.  The branch is wave-uniform.
 QINCO_DEV void wave_argmin(float& v, int& i) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    float ov = __shfl_xor(v, off);
-    int oi = __shfl_xor(i, off);
-    bool take = (ov < v) || (ov == v && oi < i);
-    v = take ? ov : v;
-    i = take ? oi : i;
+  float m = v;
+  m = fminf(m, dpp_f<0xB1>(m));
+  m = fminf(m, dpp_f<0x4E>(m));
+  m = fminf(m, dpp_f<0x141>(m));
+  m = fminf(m, dpp_f<0x140>(m));
+  {
+    const unsigned mb = __builtin_bit_cast(unsigned, m);
+    const auto r = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
+    m = fminf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+  }
+  {
+    const unsigned mb = __builtin_bit_cast(unsigned, m);
+    const auto r = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+    m = fminf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+  }
+  const unsigned long long holders = __ballot(v == m);
+  if (__popcll(holders) == 1) {
+    i = __builtin_amdgcn_readlane(i, __ffsll((long long)holders) - 1);
+    v = m;
+  } else {
+    wave_argmin_lex(v, i);
   }
 }
 
@@ -143,9 +199,11 @@ dist_topk_kernel(const float* __restrict__ x, const float* __restrict__ xhat, in
     for (int t = 0; t < T; ++t) {
       float bv = __builtin_inff();
       int bi = 0x7fffffff;
-      for (int k = lane; k < K; k += 64) {
-        float v = dg[k];
-        if (v < bv || (v == bv && k < bi)) { bv = v; bi = k; }
+      for (int k = lane; k < K; k += 64) {  // k ascends: strict < keeps the lowest index
+        const float v = dg[k];
+        const bool take = v < bv;
+        bv = take ? v : bv;
+        bi = take ? k : bi;
       }
       wave_argmin(bv, bi);
       if (bi == 0x7fffffff) bi = 0;           // all remaining +inf/NaN: degenerate, keep in range
@@ -196,9 +254,11 @@ beam_select_kernel(const float* __restrict__ dist, const float* __restrict__ can
   for (int t = 0; t < T; ++t) {
     float bv = __builtin_inff();
     int bi = 0x7fffffff;
-    for (int k = lane; k < C; k += 64) {
-      float v = dv[k];
-      if (v < bv || (v == bv && k < bi)) { bv = v; bi = k; }
+    for (int k = lane; k < C; k += 64) {  // k ascends: strict < keeps the lowest index
+      const float v = dv[k];
+      const bool take = v < bv;
+      bv = take ? v : bv;
+      bi = take ? k : bi;
     }
     wave_argmin(bv, bi);
     if (bi == 0x7fffffff) bi = 0;

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "aux_kernels.hpp"
 #include "mlp_args.hpp"
 
 namespace qinco {
@@ -56,17 +57,22 @@ ivf_assign_kernel(const f32x4* __restrict__ cstream, const float* __restrict__ c
   // block boundary (without it every wave stalled on its 16 loads at the top of each block: 36 % of wave time in
   // s_waitcnt, matrix pipe 62 % busy).  The host pads the stream by P fragments.
   constexpr int NF = NDB * 4;                      // fragments per block of 32 centroids
-  constexpr int P = (NF % 16 == 0) ? 16 : NF;      // ring depth (divides NF so ring slots are compile-time)
+  constexpr int P = (NF % 16 != 0) ? NF : (NDB > 8 ? 8 : 16);  // ring depth (divides NF: compile-time ring slots)
   const f32x4* wp = cstream + (long)cb0 * (NF * 64) + lane;
   f32x4 ring[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
   float bestd = __builtin_inff();
   int besti = 0x7fffffff;
-  for (int cb = cb0; cb < cb1; ++cb) {
+  auto block = [&](const int cb) __attribute__((always_inline)) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // the block's centroid norms are fetched before its MFMA chain, not in the epilogue (an exposed L2 round trip
+    // per block otherwise)
+    f32x4 cn[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) cn[g] = *reinterpret_cast<const f32x4*>(cnorm + cb * 32 + 8 * g + 4 * half);
 #pragma unroll
     for (int ib = 0; ib < NDB; ++ib) {
 #pragma unroll
@@ -74,6 +80,10 @@ ivf_assign_kernel(const f32x4* __restrict__ cstream, const float* __restrict__ c
         const int i = ib * 4 + q;
         const f32x4 w = ring[i % P];
         ring[i % P] = wp[(i + P) * 64];
+        // fences: without them hipcc sinks each ring load down to its use one block later (a vmcnt(0) every 4 MFMAs),
+        // or hoists the block's 64 MFMAs above all of its loads
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], xt[ib][4 * q + e], acc, 0, 0, 0);
@@ -84,17 +94,28 @@ ivf_assign_kernel(const f32x4* __restrict__ cstream, const float* __restrict__ c
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int base = cb * 32 + 8 * g + 4 * half;
-      const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + base);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float d = __fsub_rn(__fadd_rn(xn, cn[e]), __fmul_rn(2.f, acc[4 * g + e]));
+        const float d = __fsub_rn(__fadd_rn(xn, cn[g][e]), __fmul_rn(2.f, acc[4 * g + e]));
         if (d < bestd) {  // ids grow within a lane: strict < keeps the first minimum
           bestd = d;
           besti = base + e;
         }
       }
     }
+  };
+  // two blocks per trip: hipcc waits for every outstanding load at a loop head (vmcnt of the back edge is merged
+  // conservatively); inside straight-line code the waits are counted exactly
+  int cb = cb0;
+  if constexpr (NDB <= 8) {
+    for (; cb + 1 < cb1; cb += 2) {
+      block(cb);
+      block(cb + 1);
+    }
+  } else {  // D = 768: the vectors alone take 384 registers
+    for (; cb < cb1; ++cb) block(cb);
   }
+  if (cb < cb1) block(cb);
   unsigned long long key = ivf_key(bestd, besti);
   const unsigned long long other = __shfl_xor(key, 32);
   if (other < key) key = other;
@@ -114,17 +135,6 @@ __global__ void ivf_finish_kernel(const unsigned long long* __restrict__ best, l
 // shuffle arg-min.  r = x - xhat is formed on load (blocks are streamed, so any D fits), |r|^2 on the fly.
 // The VALU version spent 6x longer on the table than on the selection (profiles: 621 us per 65 536 groups).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_argmin2(float& v, int& i) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const float ov = __shfl_xor(v, off);
-    const int oi = __shfl_xor(i, off);
-    const bool take = (ov < v) || (ov == v && oi < i);
-    v = take ? ov : v;
-    i = take ? oi : i;
-  }
-}
-
 template <int D, int NKB>
 __global__ void __launch_bounds__(256)
 dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xhat, int F,
@@ -203,22 +213,15 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
         bv[u] = __builtin_inff();
         bi[u] = 0x7fffffff;
 #pragma unroll
-        for (int k = lane; k < K; k += 64) {
+        for (int k = lane; k < K; k += 64) {  // k ascends: strict < keeps the lowest index
           const float v = dg[k];
-          if (v < bv[u] || (v == bv[u] && k < bi[u])) { bv[u] = v; bi[u] = k; }
+          const bool take = v < bv[u];
+          bv[u] = take ? v : bv[u];
+          bi[u] = take ? k : bi[u];
         }
       }
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int u = 0; u < GP; ++u) {
-          const float ov = __shfl_xor(bv[u], off);
-          const int oi = __shfl_xor(bi[u], off);
-          const bool take = (ov < bv[u]) || (ov == bv[u] && oi < bi[u]);
-          bv[u] = take ? ov : bv[u];
-          bi[u] = take ? oi : bi[u];
-        }
-      }
+      for (int u = 0; u < GP; ++u) wave_argmin(bv[u], bi[u]);  // GP independent VALU chains
 #pragma unroll
       for (int u = 0; u < GP; ++u) {
         if (gl0 + u < gend) {

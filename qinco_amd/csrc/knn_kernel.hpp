@@ -82,16 +82,19 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
   xn += __shfl_xor(xn, 32);
 
   constexpr int NF = NDB * 4;
-  constexpr int P = (NF % 16 == 0) ? 16 : NF;  // register ring, as in ivf_assign_kernel (stream padded by P)
+  constexpr int P = (NF % 16 != 0) ? NF : (NDB > 8 ? 8 : 16);  // register ring, as in ivf_assign_kernel
   const f32x4* wp = qstream + lane;
   f32x4 ring[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
   float* tp = table + n0 + j;
-  for (int qb = 0; qb < nqblocks; ++qb) {
+  auto block = [&](const int qb) __attribute__((always_inline)) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    f32x4 qn[4];  // fetched ahead of the MFMA chain (see ivf_assign_kernel)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) qn[g] = *reinterpret_cast<const f32x4*>(qnorm + qb * 32 + 8 * g + 4 * half);
 #pragma unroll
     for (int ib = 0; ib < NDB; ++ib) {
 #pragma unroll
@@ -99,6 +102,10 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
         const int i = ib * 4 + q;
         const f32x4 w = ring[i % P];
         ring[i % P] = wp[(i + P) * 64];
+        // fences: without them hipcc sinks each ring load down to its use one block later (a vmcnt(0) every 4 MFMAs),
+        // or hoists the block's 64 MFMAs above all of its loads
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], xt[ib][4 * q + e], acc, 0, 0, 0);
@@ -110,13 +117,22 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int base = qb * 32 + 8 * g + 4 * half;
-        const f32x4 qn = *reinterpret_cast<const f32x4*>(qnorm + base);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          tp[(long)(base + e) * ldt] = __fsub_rn(__fadd_rn(qn[e], xn), __fmul_rn(2.f, acc[4 * g + e]));
+          tp[(long)(base + e) * ldt] = __fsub_rn(__fadd_rn(qn[g][e], xn), __fmul_rn(2.f, acc[4 * g + e]));
       }
     }
+  };
+  int qb = 0;  // two blocks per trip (where the registers allow it): see ivf_assign_kernel
+  if constexpr (NDB <= 8) {
+    for (; qb + 1 < nqblocks; qb += 2) {
+      block(qb);
+      block(qb + 1);
+    }
+  } else {
+    for (; qb < nqblocks; ++qb) block(qb);
   }
+  if (qb < nqblocks) block(qb);
 }
 
 // ---------------------------------------------------------------------------------------------

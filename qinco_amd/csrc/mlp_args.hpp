@@ -22,20 +22,22 @@ struct StreamDims {
 };
 
 // fold = true: in_proj / bias / concat are not in the stream (the kernel starts from z = T[cid] + U[group], see
-// mlp_kernel.hpp FOLD).
-constexpr StreamDims stream_dims(int D, int DE, int DH, int P, bool fold = false, bool fold2 = false) {
+// mlp_kernel.hpp FOLD).  tile = 32: mlp_kernel (32-feature blocks, 4 fragments per block pair); tile = 16:
+// mlp16_kernel (16-feature blocks, 1 fragment per block pair, never folded).
+constexpr StreamDims stream_dims(int D, int DE, int DH, int P, bool fold = false, bool fold2 = false, int tile = 32) {
   StreamDims s{};
+  const int fpp = tile == 32 ? 4 : 1;  // fragments (256 weights) per pair of blocks
   s.FOLD2 = fold2;
-  s.NDB = D / 32;
-  s.NEB = DE / 32;
-  s.NHB = DH / 32;
+  s.NDB = D / tile;
+  s.NEB = DE / tile;
+  s.NHB = DH / tile;
   s.PROJ = (D != DE);
-  s.T_IN = (s.PROJ && !fold) ? round_up(s.NEB * s.NDB * 4, P) : 0;
-  s.T_BIAS = fold ? 0 : round_up(s.NEB * 4, P);
-  s.T_CAT = fold ? 0 : round_up(s.NEB * (s.NEB + s.NDB) * 4, P);
-  s.T_UP = round_up(s.NHB * s.NEB * 4, P);
-  s.T_DOWN = round_up(s.NEB * s.NHB * 4, P);
-  s.T_OUT = s.PROJ ? round_up(s.NDB * s.NEB * 4, P) : 0;
+  s.T_IN = (s.PROJ && !fold) ? round_up(s.NEB * s.NDB * fpp, P) : 0;
+  s.T_BIAS = fold ? 0 : round_up(s.NEB * fpp, P);
+  s.T_CAT = fold ? 0 : round_up(s.NEB * (s.NEB + s.NDB) * fpp, P);
+  s.T_UP = round_up(s.NHB * s.NEB * fpp, P);
+  s.T_DOWN = round_up(s.NEB * s.NHB * fpp, P);
+  s.T_OUT = s.PROJ ? round_up(s.NDB * s.NEB * fpp, P) : 0;
   return s;
 }
 

@@ -1,23 +1,44 @@
 // One instance of the fused-MLP kernel: compiled once per QINCO_SHAPE with -DQD= -DQDE= -DQDH= -DQP= -DQVAR=.
 #include "mlp_kernel.hpp"
+#include "mlp16_kernel.hpp"
 #include "mlp_launch.hpp"
 
 #define QINCO_CAT_(a, b, c, d, e, f) a##b##_##c##_##d##_##e##_##f
 #define QINCO_CAT(a, b, c, d, e, f) QINCO_CAT_(a, b, c, d, e, f)
 
+// The kernels that stream weights through the LDS-DMA ring run ONE workgroup per CU: the launch asks for enough extra
+// dynamic LDS that two workgroups cannot share a CU's 160 KiB.  The production shapes are exclusive anyway (512
+// registers per lane), but with small models the 16-row kernel fits 3 workgroups per CU, and then single waves read
+// wrong weight fragments now and then (about 1 wave in 100 at 1500 workgroups; deterministic and exact with one
+// workgroup per CU; fully conservative waits -- vmcnt(0) + lgkmcnt(0) before every ring barrier -- do not cure it, so
+// it is not the ring's landing / overwrite protocol).  Root cause not identified; the padding costs nothing.
+static constexpr unsigned kExclusiveLds = (QVAR & 64) ? 36u * 1024u : 0u;  // shared ring: 48 KiB static + 36 = 84 > 80
+
 extern "C" __attribute__((visibility("hidden")))
 hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::MlpArgs* a, hipStream_t stream) {
   if (a->R <= 0) return hipSuccess;
+#if (QVAR & 128)  // 16-row tile form (mlp16_kernel.hpp)
+  const long tiles = (a->R + 15) / 16;
+  const unsigned grid = (unsigned)((tiles + 3) / 4);
+  hipLaunchKernelGGL((qinco::mlp16_kernel<QD, QDE, QDH, QP>), dim3(grid), dim3(256), kExclusiveLds, stream, *a);
+#else
   const long tiles = (a->R + 31) / 32;
   const unsigned grid = (unsigned)((tiles + 3) / 4);
-  hipLaunchKernelGGL((qinco::mlp_kernel<QD, QDE, QDH, QP, QVAR>), dim3(grid), dim3(256), 0, stream, *a);
+  hipLaunchKernelGGL((qinco::mlp_kernel<QD, QDE, QDH, QP, QVAR>), dim3(grid), dim3(256), kExclusiveLds, stream, *a);
+#endif
   return hipGetLastError();
 }
 
 extern "C" __attribute__((visibility("hidden")))
 hipError_t QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::XprojArgs* a, hipStream_t stream) {
+#if (QVAR & 128)
+  (void)a;
+  (void)stream;
+  return hipErrorNotSupported;  // the 16-row form is never folded
+#else
   if (a->G <= 0) return hipSuccess;
   const unsigned grid = (unsigned)((a->G + 127) / 128);
   hipLaunchKernelGGL((qinco::xproj_kernel<QD, QDE, QDH>), dim3(grid), dim3(256), 0, stream, *a);
   return hipGetLastError();
+#endif
 }

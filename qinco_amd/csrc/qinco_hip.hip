@@ -204,6 +204,31 @@ static void pack_bias(std::vector<float>& s, const float* b, int O, int T) {
   pad_to(s, start, T);
 }
 
+// 16-row tile form (mlp16_kernel.hpp): fragment (ob, ib) = the 16 x 16 weight block, lane l, component r =
+// W[ob*16 + (l & 15)][ib*16 + 4 (l >> 4) + r]; every section K-outer (for ib: for ob).
+static void pack16_kouter(std::vector<float>& s, const float* W, int O, int I, int T) {
+  size_t start = s.size();
+  for (int ib = 0; ib < I / 16; ++ib)
+    for (int ob = 0; ob < O / 16; ++ob) {
+      size_t base = s.size();
+      s.resize(base + 256);
+      for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < 4; ++r) s[base + l * 4 + r] = W[(size_t)(ob * 16 + (l & 15)) * I + ib * 16 + 4 * (l >> 4) + r];
+    }
+  pad_to(s, start, T);
+}
+
+static void pack16_bias(std::vector<float>& s, const float* b, int O, int T) {
+  size_t start = s.size();
+  for (int ob = 0; ob < O / 16; ++ob) {
+    size_t base = s.size();
+    s.resize(base + 256);
+    for (int l = 0; l < 64; ++l)
+      for (int r = 0; r < 4; ++r) s[base + l * 4 + r] = b[ob * 16 + 4 * (l >> 4) + r];
+  }
+  pad_to(s, start, T);
+}
+
 static int upload(qinco_handle_s* h, float** dst, const float* src, size_t count) {
   int rc = dev_alloc(h, dst, count);
   if (rc) return rc;
@@ -417,7 +442,8 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   }
   h->fold = fn && (fn->var & 16);
   h->fold2 = fn && (fn->var & 32);
-  h->sd = stream_dims(d.D, d.De, d.Dh, kRing, h->fold, h->fold2);
+  const bool tile16 = fn && (fn->var & 128);
+  h->sd = stream_dims(d.D, d.De, d.Dh, kRing, h->fold, h->fold2, tile16 ? 16 : 32);
   int rc = 0;
   auto bail = [&](int code) {
     qinco_destroy(h);
@@ -469,21 +495,33 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
     if (sd.PROJ && (!w->in_proj[m] || !w->out_proj[m]))
       return bail(fail(QINCO_ERR_INVALID, "qinco_create: in/out_proj[%d] is null", m));
     if (!w->cat_w[m] || !w->cat_b[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: concat weights[%d] null", m));
-    if (h->fold) {
+    if (tile16) {
+      if (sd.PROJ) pack16_kouter(s, w->in_proj[m], d.De, d.D, sd.T_IN);
+      pack16_bias(s, w->cat_b[m], d.De, sd.T_BIAS);
+      pack16_kouter(s, w->cat_w[m], d.De, d.De + d.D, sd.T_CAT);
+      for (int l = 0; l < d.L; ++l) {
+        const float* up = w->up[(size_t)m * d.L + l];
+        const float* dn = w->down[(size_t)m * d.L + l];
+        if (!up || !dn) return bail(fail(QINCO_ERR_INVALID, "qinco_create: FFN weights[%d][%d] null", m, l));
+        pack16_kouter(s, up, d.Dh, d.De, sd.T_UP);
+        pack16_kouter(s, dn, d.De, d.Dh, sd.T_DOWN);
+      }
+      if (sd.PROJ) pack16_kouter(s, w->out_proj[m], d.D, d.De, sd.T_OUT);
+    } else if (h->fold) {
       if ((rc = build_fold_tables(h, w, m))) return bail(rc);
     } else {
       if (sd.PROJ) pack_kouter(s, w->in_proj[m], d.De, d.D, sd.T_IN);
       pack_bias(s, w->cat_b[m], d.De, sd.T_BIAS);
       pack_kouter(s, w->cat_w[m], d.De, d.De + d.D, sd.T_CAT);
     }
-    for (int l = 0; l < d.L; ++l) {
+    for (int l = 0; l < d.L && !tile16; ++l) {
       const float* up = w->up[(size_t)m * d.L + l];
       const float* dn = w->down[(size_t)m * d.L + l];
       if (!up || !dn) return bail(fail(QINCO_ERR_INVALID, "qinco_create: FFN weights[%d][%d] null", m, l));
       if (!(h->fold2 && l == 0)) pack_obouter(s, up, d.Dh, d.De, sd.T_UP);
       pack_obouter(s, dn, d.De, d.Dh, sd.T_DOWN);
     }
-    if (sd.PROJ) pack_obouter(s, w->out_proj[m], d.D, d.De, sd.T_OUT);
+    if (sd.PROJ && !tile16) pack_obouter(s, w->out_proj[m], d.D, d.De, sd.T_OUT);
     if ((long)(s.size() / 256) != sd.total(d.L)) return bail(fail(QINCO_ERR_INVALID, "internal: stream size mismatch"));
     s.resize(s.size() + (size_t)kRing * 256, 0.f);  // the ring prefetches P fragments past the end
     float* ds = nullptr;

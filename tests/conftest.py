@@ -28,6 +28,7 @@ def golden_cases():
         "C2_qinco2L_8x8_b8": (preset("qinco2-L", D=128, M=8, B=8), 1236),
         "C2_qinco2L_8x8_b1": (preset("qinco2-L", D=128, M=8, B=1), 1236),
         "C4_qinco2L_d768_b8": (preset("qinco2-L", D=768, M=4, B=8), 1238),
+        "qinco1_d768": (preset("qinco1", D=768, M=3), 1241),
         "tiny_ivf_beam": (QincoConfig(D=32, M=3, K=256, L=2, de=64, dh=96, A=4, B=8, ivf_K=2048), 15),
         "tiny_ivf_greedy_id": (QincoConfig(D=32, M=3, K=256, L=2, de=None, dh=64, A=8, B=1, ivf_K=1024), 16),
         "ivf_qinco2S_d128": (preset("qinco2-S", D=128, M=4, B=8, ivf_K=65536), 1240),

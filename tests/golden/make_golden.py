@@ -79,6 +79,7 @@ CASES = {
     "C2_qinco2L_8x8_b8": (preset("qinco2-L", D=128, M=8, B=8), 1236, 64),
     "C2_qinco2L_8x8_b1": (preset("qinco2-L", D=128, M=8, B=1), 1236, 64),
     "C4_qinco2L_d768_b8": (preset("qinco2-L", D=768, M=4, B=8), 1238, 32),
+    "qinco1_d768": (preset("qinco1", D=768, M=3), 1241, 32),   # De = D = 768: the 16-row tile kernel's shape
     # IVF-QINCo: coarse step of ivf_K centroids, beam_0 = 1, first QINCo step takes max(A, B)
     "tiny_ivf_beam": (QincoConfig(D=32, M=3, K=256, L=2, de=64, dh=96, A=4, B=8, ivf_K=2048), 15, 256),
     "tiny_ivf_greedy_id": (QincoConfig(D=32, M=3, K=256, L=2, de=None, dh=64, A=8, B=1, ivf_K=1024), 16, 256),

@@ -297,3 +297,28 @@ def test_model_without_ffn_blocks_uses_fallback_instance():
     want = make_oracle(cfg, sd)(x, step="encode").T
     assert (eng.encode(x) != want).any(axis=1).sum() <= 1
     eng.close()
+
+
+@pytest.mark.parametrize("variant", [None, "48,196"], ids=["production", "tile16"])
+def test_small_models_at_large_batches_are_exact_and_deterministic(variant, monkeypatch):
+    """Small models leave room for several workgroups per CU; the ring kernels must stay exact there (the 16-row kernel
+    gave rare per-wave corruption with 3 workgroups per CU until its launch was made exclusive, csrc/mlp_inst.hip)."""
+    from qinco_amd import QincoConfig, QincoEngine, synth_state_dict, synth_vectors
+    if variant:
+        monkeypatch.setenv("QINCO_MLP_VARIANT", variant)
+    for kw in (dict(A=0, B=1, qinco1_mode=True), dict(A=32, B=4), dict(A=8, B=4, de=64, dh=96)):
+        base = dict(D=32, M=3, K=256, L=2, de=None, dh=64, qinco1_mode=False)
+        base.update(kw)
+        cfg = QincoConfig(**base)
+        sd = synth_state_dict(cfg, 13)
+        x = synth_vectors(cfg, sd, 3000, seed=999)
+        oracle = make_oracle(cfg, sd)
+        want = oracle(x, step="encode").T
+        eng = QincoEngine(cfg, sd, max_batch=4096)
+        runs = [eng.encode(x, return_xhat=True) for _ in range(3)]
+        for codes, xhat in runs:
+            assert np.array_equal(codes, runs[0][0]) and np.array_equal(xhat, runs[0][1])
+        assert (runs[0][0] != want).any(axis=1).sum() <= 3000 // 500
+        ref = (oracle(runs[0][0].T, step="decode") - oracle.data_mean) / oracle.data_std
+        assert np.abs(runs[0][1] - ref).max() / np.abs(ref).max() < REL_TOL
+        eng.close()

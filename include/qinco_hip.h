@@ -110,6 +110,13 @@ QINCO_API int qinco_profile_read(qinco_handle h, double* mlp_ms, int64_t* mlp_la
 QINCO_API double qinco_flops_per_vector_encode(qinco_handle h);
 QINCO_API double qinco_flops_per_vector_decode(qinco_handle h);
 
+/* IVF models: statistics of the most recent IVF assignment of the handle (the last chunk of the last encode call).
+ * The assignment runs two fp16 matrix-core filter passes and an exact fp32 pass over the surviving candidates
+ * (csrc/ivf_f16_kernel.hpp); *candidates = pairs the exact pass evaluated, *fell_back = 1 if the exact fp32 table
+ * kernel had to redo the batch (candidate list full, or inputs outside the fp16 range).  Both 0 when the handle has no
+ * fp16 copy (QINCO_IVF_FP32=1, or centroids outside the fp16 range).  Synchronises the device. */
+QINCO_API int qinco_ivf_last_stats(qinco_handle h, int64_t* candidates, int32_t* fell_back);
+
 /* 1 if a fused-MLP kernel instance exists for (D, De, Dh). */
 QINCO_API int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh);
 

@@ -18,7 +18,7 @@ API_SYMBOLS = [
     "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
     "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
-    "qinco_knn_create", "qinco_knn_destroy", "qinco_knn_search", "qinco_knn_search_host", "qinco_sqerr_sum",
+    "qinco_ivf_last_stats", "qinco_knn_create", "qinco_knn_destroy", "qinco_knn_search", "qinco_knn_search_host", "qinco_sqerr_sum",
 ]
 
 
@@ -98,6 +98,7 @@ def load() -> C.CDLL:
     lib.qinco_flops_per_vector_decode.argtypes = [vp]
     lib.qinco_flops_per_vector_decode.restype = dbl
     lib.qinco_shape_supported.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.qinco_ivf_last_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_int32)]
     I32P = C.POINTER(C.c_int32)
     lib.qinco_lut_create.argtypes = [FP, C.c_int32, i64, C.c_int32, I32P, I32P, i64, C.POINTER(vp)]
     lib.qinco_lut_destroy.argtypes = [vp]

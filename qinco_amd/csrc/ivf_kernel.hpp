@@ -24,7 +24,11 @@ __device__ __forceinline__ unsigned long long ivf_key(float d, int idx) {
 template <int D>
 __global__ void __launch_bounds__(256)
 ivf_assign_kernel(const f32x4* __restrict__ cstream, const float* __restrict__ cnorm, int nblocks, int blocks_per_slice,
-                  const float* __restrict__ x, long N, unsigned long long* __restrict__ best) {
+                  const float* __restrict__ x, long N, unsigned long long* __restrict__ best,
+                  const int* __restrict__ only_if) {
+  // only_if != nullptr: this launch is the exact fall-back behind the fp16-filter passes (ivf_f16_kernel.hpp) and
+  // does nothing unless they raised their overflow flag
+  if (only_if && *only_if == 0) return;
   constexpr int NDB = D / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;

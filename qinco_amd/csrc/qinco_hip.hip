@@ -13,6 +13,7 @@
 
 #include "abi_util.hpp"
 #include "aux_kernels.hpp"
+#include "ivf_f16_kernel.hpp"
 #include "ivf_kernel.hpp"
 #include "lut_kernel.hpp"
 #include "mlp_args.hpp"
@@ -91,6 +92,14 @@ struct qinco_handle_s {
   int K0 = 0;                       // rows of codebook[0] (ivf_K or K)
   f32x4* ivf_stream = nullptr;      // centroids packed as MFMA A-operand fragments
   unsigned long long* ivf_best = nullptr;  // (max_batch) merged (distance, id) keys
+  // fp16-filter passes of the IVF assignment (ivf_f16_kernel.hpp)
+  bool ivf_f16 = false;
+  void* ivf_h16 = nullptr;           // centroids as fp16 MFMA fragments
+  float* ivf_cnorm_half = nullptr;   // |c|^2 / 2
+  float ivf_cmax = 0.f;
+  unsigned* ivf_amin = nullptr;      // (max_batch) approximate minima
+  int* ivf_cand = nullptr;           // [count, overflow, pad, pad][vec (cap)][id (cap)]
+  int ivf_cand_cap = 0;
 
   // scratch (sized for d.max_batch, A, B)
   int64_t cap_n = 0;
@@ -250,6 +259,44 @@ static int upload_fragments(qinco_handle_s* h, const float* cb, int K, int D, f3
   return rc;
 }
 
+// fp16 copy of the IVF centroids for the filter passes (ivf_f16_kernel.hpp): fragment (block of 32 centroids, k-step of
+// 16 features): lane l, 8 halfs = C[block*32 + (l & 31)][k*16 + 8 (l >> 5) + 0..7], rounded to nearest even.
+static int build_ivf_f16(qinco_handle_s* h, const float* cb) {
+  const int K = h->d.ivf_K, D = h->d.D, NK = D / 16;
+  float amax = 0.f;
+  double n2max = 0.0;
+  std::vector<float> nh(K);
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    double s2 = 0.0;
+    for (int j = 0; j < D; ++j) {
+      const float v = cb[(size_t)k * D + j];
+      s = fmaf(v, v, s);
+      s2 += (double)v * v;
+      amax = fmaxf(amax, fabsf(v));
+    }
+    nh[k] = 0.5f * s;  // same |c|^2 as upload_with_norms, halved exactly
+    if (s2 > n2max) n2max = s2;
+  }
+  if (!(amax < 60000.f)) return 0;  // outside the fp16 range: the exact fp32 kernel is used on its own
+  std::vector<_Float16> s((size_t)K * D + (size_t)8 * 512);
+  size_t o = 0;
+  for (int b = 0; b < K / 32; ++b)
+    for (int k = 0; k < NK; ++k)
+      for (int l = 0; l < 64; ++l)
+        for (int e = 0; e < 8; ++e) s[o++] = (_Float16)cb[(size_t)(b * 32 + (l & 31)) * D + k * 16 + 8 * (l >> 5) + e];
+  for (; o < s.size(); ++o) s[o] = (_Float16)0.f;
+  float* dh = nullptr;
+  int rc = dev_alloc(h, &dh, (s.size() + 1) / 2);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(dh, s.data(), s.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  h->ivf_h16 = dh;
+  if ((rc = upload(h, &h->ivf_cnorm_half, nh.data(), K))) return rc;
+  h->ivf_cmax = (float)(std::sqrt(n2max) * 1.000001);
+  h->ivf_f16 = true;
+  return 0;
+}
+
 static int upload_with_norms(qinco_handle_s* h, const float* cb, int K, int D, float** d_cb, float** d_norm) {
   int rc = upload(h, d_cb, cb, (size_t)K * D);
   if (rc) return rc;
@@ -269,12 +316,14 @@ static int ensure_scratch(qinco_handle_s* h) {
   const qinco_desc& d = h->d;
   if (h->cap_n == d.max_batch && h->cap_A == h->A && h->cap_B == h->B) return 0;
   void* old[] = {h->xn, h->xhat[0], h->xhat[1], h->hist[0], h->hist[1], h->top_ids, h->cand, h->dist, h->ivf_best,
-                 h->uproj};
+                 h->uproj, h->ivf_amin, h->ivf_cand};
   HIP_TRY(hipDeviceSynchronize());
   for (void* p : old) dev_free(h, p);
   h->xn = h->xhat[0] = h->xhat[1] = h->cand = h->dist = nullptr;
   h->hist[0] = h->hist[1] = h->top_ids = nullptr;
   h->ivf_best = nullptr;
+  h->ivf_amin = nullptr;
+  h->ivf_cand = nullptr;
   h->uproj = nullptr;
   h->cap_n = 0;
   const size_t n = (size_t)d.max_batch;
@@ -292,6 +341,11 @@ static int ensure_scratch(qinco_handle_s* h) {
   if ((rc = dev_alloc(h, &h->cand, n * Bm * Ae * d.D))) return rc;
   if ((rc = dev_alloc(h, &h->dist, n * Bm * Ae))) return rc;
   if (d.ivf_K > 0 && (rc = dev_alloc(h, &h->ivf_best, n))) return rc;
+  if (h->ivf_f16) {
+    h->ivf_cand_cap = (int)(16 * n + 4096);
+    if ((rc = dev_alloc(h, &h->ivf_amin, n))) return rc;
+    if ((rc = dev_alloc(h, &h->ivf_cand, 4 + 2 * (size_t)h->ivf_cand_cap))) return rc;
+  }
   if (h->fold && (rc = dev_alloc(h, &h->uproj, n * Bm * (d.De + (h->fold2 ? d.Dh : 0))))) return rc;
   h->cap_n = d.max_batch;
   h->cap_A = h->A;
@@ -478,6 +532,7 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
     if (m == 0) {
       if (d.ivf_K > 0) {
         if ((rc = upload_fragments(h, w->codebook[0], d.ivf_K, d.D, &h->ivf_stream))) return bail(rc);
+        if (!getenv("QINCO_IVF_FP32") && (rc = build_ivf_f16(h, w->codebook[0]))) return bail(rc);
       } else if (mfma_table_ok(d)) {
         if ((rc = upload_fragments(h, w->codebook[0], d.K, d.D, &h->cb_stream[0]))) return bail(rc);
       }
@@ -639,31 +694,82 @@ static int launch_dist_topk(qinco_handle_s* h, const float* x, const float* xhat
 }
 
 template <int D>
-static void launch_ivf_inst(qinco_handle_s* h, long n, int nblocks, int bps, int slices, hipStream_t st) {
+static void launch_ivf_inst(qinco_handle_s* h, long n, int nblocks, int bps, int slices, const int* only_if, hipStream_t st) {
   hipLaunchKernelGGL(ivf_assign_kernel<D>, dim3((unsigned)((n + 127) / 128), (unsigned)slices), dim3(256), 0, st,
-                     h->ivf_stream, h->cnorm[0], nblocks, bps, h->xn, n, h->ivf_best);
+                     h->ivf_stream, h->cnorm[0], nblocks, bps, h->xn, n, h->ivf_best, only_if);
 }
 
-// IVF step 0: codes0 = argmin over the ivf_K centroids (IVFBook.quantize, qinco_base.py:146-163) -> top_ids[n]
+template <int D>
+static void launch_ivf_f16_inst(const IvfF16Args& a, long tiles, int slices, hipStream_t st) {
+  hipLaunchKernelGGL((ivf_f16_kernel<D, 0>), dim3((unsigned)tiles, (unsigned)slices), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((ivf_f16_kernel<D, 1>), dim3((unsigned)tiles, (unsigned)slices), dim3(256), 0, st, a);
+}
+
+static void ivf_grid(long tiles, int nblocks, int target_wgs, int* bps, long* slices) {
+  long s = (target_wgs + tiles - 1) / tiles;
+  if (s > nblocks) s = nblocks;
+  if (s < 1) s = 1;
+  *bps = (int)((nblocks + s - 1) / s);
+  *slices = (nblocks + *bps - 1) / *bps;
+}
+
+// IVF step 0: codes0 = argmin over the ivf_K centroids (IVFBook.quantize, qinco_base.py:146-163) -> top_ids[n].
+// fp16 filter passes A, B + exact pass C (ivf_f16_kernel.hpp), then the exact fp32 table kernel, which returns at once
+// unless the filter raised its overflow flag; without the fp16 copy the fp32 kernel does the whole job.
 static int launch_ivf_assign(qinco_handle_s* h, long n, hipStream_t st) {
   const qinco_desc& d = h->d;
   const int nblocks = d.ivf_K / 32;
-  const long tiles = (n + 127) / 128;
-  long slices = (2048 + tiles - 1) / tiles;  // aim at >= 2048 workgroups (8 per CU: low-register kernel)
-  if (slices > nblocks) slices = nblocks;
-  if (slices < 1) slices = 1;
-  const int bps = (int)((nblocks + slices - 1) / slices);
-  slices = (nblocks + bps - 1) / bps;
   HIP_TRY(hipMemsetAsync(h->ivf_best, 0xFF, (size_t)n * sizeof(unsigned long long), st));
-  switch (d.D) {
-    case 32: launch_ivf_inst<32>(h, n, nblocks, bps, (int)slices, st); break;
-    case 96: launch_ivf_inst<96>(h, n, nblocks, bps, (int)slices, st); break;
-    case 128: launch_ivf_inst<128>(h, n, nblocks, bps, (int)slices, st); break;
-    case 256: launch_ivf_inst<256>(h, n, nblocks, bps, (int)slices, st); break;
-    case 768: launch_ivf_inst<768>(h, n, nblocks, bps, (int)slices, st); break;
-    default: return fail(QINCO_ERR_UNSUPPORTED, "no IVF kernel instance for D=%d", d.D);
+  const int* only_if = nullptr;
+  if (h->ivf_f16) {
+    HIP_TRY(hipMemsetAsync(h->ivf_amin, 0xFF, (size_t)n * sizeof(unsigned), st));
+    HIP_TRY(hipMemsetAsync(h->ivf_cand, 0, 4 * sizeof(int), st));
+    IvfF16Args a{};
+    a.cstream = reinterpret_cast<const h16x8*>(h->ivf_h16);
+    a.cnorm_half = h->ivf_cnorm_half;
+    a.nblocks = nblocks;
+    a.x = h->xn;
+    a.N = n;
+    a.approx_min = h->ivf_amin;
+    a.cmax = h->ivf_cmax;
+    a.cand_count = h->ivf_cand;
+    a.overflow = h->ivf_cand + 1;
+    a.cand_cap = h->ivf_cand_cap;
+    a.cand_vec = h->ivf_cand + 4;
+    a.cand_id = h->ivf_cand + 4 + h->ivf_cand_cap;
+    const int vs = d.D <= 256 ? 2 : 1;
+    const long tiles = (n + 128 * vs - 1) / (128 * vs);
+    long slices;
+    ivf_grid(tiles, nblocks, 2048, &a.blocks_per_slice, &slices);
+    switch (d.D) {
+      case 32: launch_ivf_f16_inst<32>(a, tiles, (int)slices, st); break;
+      case 96: launch_ivf_f16_inst<96>(a, tiles, (int)slices, st); break;
+      case 128: launch_ivf_f16_inst<128>(a, tiles, (int)slices, st); break;
+      case 256: launch_ivf_f16_inst<256>(a, tiles, (int)slices, st); break;
+      case 768: launch_ivf_f16_inst<768>(a, tiles, (int)slices, st); break;
+      default: return fail(QINCO_ERR_UNSUPPORTED, "no IVF kernel instance for D=%d", d.D);
+    }
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(ivf_exact_kernel, dim3(512), dim3(256), 0, st, a.cand_count, a.cand_cap, a.overflow, a.cand_vec, a.cand_id, h->xn,
+                       h->codebook[0], h->cnorm[0], d.D, h->ivf_best);
+    HIP_TRY(hipGetLastError());
+    only_if = a.overflow;
   }
-  HIP_TRY(hipGetLastError());
+  {
+    const long tiles = (n + 127) / 128;
+    int bps;
+    long slices;
+    ivf_grid(tiles, nblocks, 2048, &bps, &slices);  // aim at >= 2048 workgroups
+    switch (d.D) {
+      case 32: launch_ivf_inst<32>(h, n, nblocks, bps, (int)slices, only_if, st); break;
+      case 96: launch_ivf_inst<96>(h, n, nblocks, bps, (int)slices, only_if, st); break;
+      case 128: launch_ivf_inst<128>(h, n, nblocks, bps, (int)slices, only_if, st); break;
+      case 256: launch_ivf_inst<256>(h, n, nblocks, bps, (int)slices, only_if, st); break;
+      case 768: launch_ivf_inst<768>(h, n, nblocks, bps, (int)slices, only_if, st); break;
+      default: return fail(QINCO_ERR_UNSUPPORTED, "no IVF kernel instance for D=%d", d.D);
+    }
+    HIP_TRY(hipGetLastError());
+  }
   hipLaunchKernelGGL(ivf_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->ivf_best, n, h->top_ids);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -939,6 +1045,20 @@ extern "C" double qinco_flops_per_vector_encode(qinco_handle h) {
     F = Fout < F * Ae ? Fout : (int)(F * Ae);
   }
   return total;
+}
+
+extern "C" int qinco_ivf_last_stats(qinco_handle h, int64_t* candidates, int32_t* fell_back) {
+  if (!h || !candidates || !fell_back) return fail(QINCO_ERR_INVALID, "qinco_ivf_last_stats: null argument");
+  *candidates = 0;
+  *fell_back = 0;
+  if (!h->ivf_f16 || !h->ivf_cand) return QINCO_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  int v[2] = {0, 0};
+  HIP_TRY(hipMemcpy(v, h->ivf_cand, sizeof(v), hipMemcpyDeviceToHost));
+  *candidates = v[0] < h->ivf_cand_cap ? v[0] : h->ivf_cand_cap;
+  *fell_back = v[1] != 0;
+  return QINCO_OK;
 }
 
 extern "C" double qinco_flops_per_vector_decode(qinco_handle h) {

@@ -190,6 +190,12 @@ class QincoEngine:
         _lib.check(self.lib.qinco_profile_read(self._h, C.byref(ms), C.byref(cnt), C.byref(fl)))
         return {"mlp_ms": ms.value, "mlp_launches": cnt.value, "mlp_flops": fl.value}
 
+    def ivf_last_stats(self) -> dict:
+        """IVF models: exact-pass candidate pairs and fall-back flag of the last IVF assignment (qinco_ivf_last_stats)."""
+        c, f = C.c_int64(), C.c_int32()
+        _lib.check(self.lib.qinco_ivf_last_stats(self._h, C.byref(c), C.byref(f)))
+        return {"candidates": c.value, "fell_back": bool(f.value)}
+
     def flops_per_vector(self, what: str = "encode") -> float:
         fn = self.lib.qinco_flops_per_vector_encode if what == "encode" else self.lib.qinco_flops_per_vector_decode
         return float(fn(self._h))

@@ -55,11 +55,16 @@ def main():
                 pr = eng.profile_read()
                 eng.profile_enable(False)
                 tf = pr["mlp_flops"] / (pr["mlp_ms"] * 1e-3) / 1e12 if pr["mlp_ms"] else 0.0
-                print(json.dumps({"workload": wl, "mode": mode, "A": eng.A, "B": B, "vectors_per_step": nvec,
-                                  "vectors_per_s": args.steps * nvec / dt, "us_per_vector": dt / (args.steps * nvec) * 1e6,
-                                  "gflop_per_vector": eng.flops_per_vector(mode) / 1e9,
-                                  "mlp_tflops": tf, "mlp_frac_of_fp32_mfma_peak": tf / PEAK,
-                                  "mlp_share_of_time": pr["mlp_ms"] * 1e-3 / dt}), flush=True)
+                rec = {"workload": wl, "mode": mode, "A": eng.A, "B": B, "vectors_per_step": nvec,
+                       "vectors_per_s": args.steps * nvec / dt, "us_per_vector": dt / (args.steps * nvec) * 1e6,
+                       "gflop_per_vector": eng.flops_per_vector(mode) / 1e9,
+                       "mlp_tflops": tf, "mlp_frac_of_fp32_mfma_peak": tf / PEAK,
+                       "mlp_share_of_time": pr["mlp_ms"] * 1e-3 / dt}
+                if cfg0.ivf and mode == "encode":
+                    st = eng.ivf_last_stats()
+                    rec["ivf_exact_candidates_per_vector"] = st["candidates"] / nvec
+                    rec["ivf_fell_back"] = st["fell_back"]
+                print(json.dumps(rec), flush=True)
         if args.host:   # numpy in / numpy out through qinco_encode_host: H2D of x and D2H of the codes are inside the time
             eng.set_beam(B=beams[-1])
             xh = x.cpu().numpy()

@@ -322,3 +322,65 @@ def test_small_models_at_large_batches_are_exact_and_deterministic(variant, monk
         ref = (oracle(runs[0][0].T, step="decode") - oracle.data_mean) / oracle.data_std
         assert np.abs(runs[0][1] - ref).max() / np.abs(ref).max() < REL_TOL
         eng.close()
+
+
+def _ivf_cfg(D, ivf_K):
+    from qinco_amd import QincoConfig
+    return QincoConfig(D=D, M=1, K=256, L=1, de=None, dh=(64 if D == 32 else 256), A=4, B=1, ivf_K=ivf_K)   # IVF id + one QINCo step
+
+
+@pytest.mark.parametrize("D,ivf_K,n", [(32, 4096, 3000), (96, 2048, 1000), (128, 32768, 2500), (256, 1024, 700), (768, 2048, 300)])
+def test_ivf_fp16_filter_equals_exact_table(D, ivf_K, n, monkeypatch):
+    """The fp16-filter + exact-candidates assignment against numpy's argmin of the reference formula and against the
+    fp32 table kernel alone (QINCO_IVF_FP32=1): equal wherever the two best distances are not a rounding-level tie."""
+    from oracle.qinco_oracle import approx_pairwise_distance
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    cfg = _ivf_cfg(D, ivf_K)
+    sd = synth_state_dict(cfg, 77 + D)
+    x = synth_vectors(cfg, sd, n, seed=5)
+    eng = QincoEngine(cfg, sd, max_batch=4096)
+    got = eng.encode(x)[:, 0]
+    st = eng.ivf_last_stats()
+    assert not st["fell_back"] and n <= st["candidates"] < 8 * n, st
+    eng.close()
+    monkeypatch.setenv("QINCO_IVF_FP32", "1")
+    eng32 = QincoEngine(cfg, sd, max_batch=4096)
+    got32 = eng32.encode(x)[:, 0]
+    assert eng32.ivf_last_stats() == {"candidates": 0, "fell_back": False}
+    eng32.close()
+    xn = ((x - sd["data_mean"]) / sd["data_std"]).astype(np.float32)
+    d = approx_pairwise_distance(xn, sd["steps.0.ivf_centroids.weight"].astype(np.float32))
+    order = np.argsort(d, axis=1, kind="stable")[:, :2]
+    best, second = np.take_along_axis(d, order[:, :1], 1)[:, 0], np.take_along_axis(d, order[:, 1:2], 1)[:, 0]
+    clear = (second - best) > 2e-5 * np.abs(second)
+    assert np.array_equal(got[clear], order[clear, 0]) and np.array_equal(got32[clear], order[clear, 0])
+    assert (got != got32).sum() <= (~clear).sum()
+
+
+def test_ivf_fp16_filter_falls_back_on_ties_and_range(monkeypatch):
+    """Duplicated centroids make every copy a candidate (the list overflows) and huge inputs leave the fp16 range: both
+    must take the exact fp32 kernel and still give argmin with the lowest index among exact ties."""
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    cfg = _ivf_cfg(32, 8192)
+    sd = synth_state_dict(cfg, 3)
+    cent = sd["steps.0.ivf_centroids.weight"]
+    cent[:] = np.repeat(cent[:4], 2048, axis=0)        # 4 distinct rows, 2048 exact copies each
+    x = synth_vectors(cfg, sd, 600, seed=9)
+    eng = QincoEngine(cfg, sd, max_batch=1024)
+    got = eng.encode(x)[:, 0]
+    assert eng.ivf_last_stats()["fell_back"]
+    xn = ((x - sd["data_mean"]) / sd["data_std"]).astype(np.float32)
+    d = ((xn[:, None, :] - cent[None, ::2048, :]) ** 2).sum(-1)
+    assert np.array_equal(got, d.argmin(1) * 2048)     # first copy of the nearest distinct row
+    eng.close()
+    sd2 = synth_state_dict(cfg, 4)
+    eng2 = QincoEngine(cfg, sd2, max_batch=1024)
+    xbig = synth_vectors(cfg, sd2, 64, seed=1)
+    xbig[7, 3] = 1.0e7 * float(sd2["data_std"])       # normalised value far outside the fp16 range
+    got2 = eng2.encode(xbig)[:, 0]
+    assert eng2.ivf_last_stats()["fell_back"]
+    monkeypatch.setenv("QINCO_IVF_FP32", "1")
+    eng3 = QincoEngine(cfg, sd2, max_batch=1024)
+    assert np.array_equal(got2, eng3.encode(xbig)[:, 0])
+    eng2.close()
+    eng3.close()

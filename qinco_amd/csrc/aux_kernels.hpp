@@ -79,6 +79,54 @@ QINCO_DEV void wave_argmin(float& v, int& i) {
   }
 }
 
+// N independent reductions side by side: the N value chains interleave (each level of one chain waits on the
+// previous one), and the tie test is ONE wave-uniform branch for all N instead of a branch per reduction -- a branch
+// after every reduction serialised them (rocprofv3: ~850 cycles per reduction in dist_topk_mfma_kernel).
+QINCO_DEV float min_nn(float a, float b) { return b < a ? b : a; }   // no NaN canonicalisation (v_cmp + v_cndmask)
+template <int N>
+QINCO_DEV void wave_argmin_n(float (&v)[N], int (&i)[N]) {
+  float m[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) m[u] = v[u];
+#pragma unroll
+  for (int u = 0; u < N; ++u) m[u] = min_nn(m[u], dpp_f<0xB1>(m[u]));
+#pragma unroll
+  for (int u = 0; u < N; ++u) m[u] = min_nn(m[u], dpp_f<0x4E>(m[u]));
+#pragma unroll
+  for (int u = 0; u < N; ++u) m[u] = min_nn(m[u], dpp_f<0x141>(m[u]));
+#pragma unroll
+  for (int u = 0; u < N; ++u) m[u] = min_nn(m[u], dpp_f<0x140>(m[u]));
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const unsigned mb = __builtin_bit_cast(unsigned, m[u]);
+    const auto r = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
+    m[u] = min_nn(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+  }
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const unsigned mb = __builtin_bit_cast(unsigned, m[u]);
+    const auto r = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+    m[u] = min_nn(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+  }
+  unsigned long long holders[N];
+  bool unique = true;
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    holders[u] = __ballot(v[u] == m[u]);
+    unique &= __popcll(holders[u]) == 1;
+  }
+  if (unique) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      i[u] = __builtin_amdgcn_readlane(i[u], __ffsll((long long)holders[u]) - 1);
+      v[u] = m[u];
+    }
+  } else {  // exact ties somewhere (or no finite value left): lexicographic, lowest index wins
+#pragma unroll
+    for (int u = 0; u < N; ++u) wave_argmin_lex(v[u], i[u]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K8: x_n = (x - mean) / std   (qinco_inference.py:277).  x is fp32 or uint8 rows with a byte stride
 // (bvecs rows are d+4 bytes apart: search_tasks.py:109-110 converts the raw slice with .to(float32)).

@@ -160,17 +160,32 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
   for (int cb = 0; cb < NKB; ++cb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
-  float rn = 0.f;
+  // Codebook fragments in the order they are used (feature block, q, codeword block) through a fenced register ring,
+  // the raw x / xhat rows of the next feature block fetched before the current block's MFMAs.  Without this every one
+  // of the 32 * NDB fragments exposed an L2 round trip to the single wave of its SIMD (rocprofv3: 200 us for ONE
+  // workgroup, of which the MFMAs are 14 us).
+  constexpr int NFR = NDB * 4 * NKB, P = NDB > 8 ? 8 : 16;
+  auto frag_ofs = [](int i) { return (((i % NKB) * NDB + i / (4 * NKB)) * 4 + (i / NKB) % 4) * 64; };
+  f32x4 ring[P];
 #pragma unroll
+  for (int i = 0; i < P; ++i) ring[i] = wp[frag_ofs(i)];
+  f32x4 xr[4], hr[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    xr[q] = *reinterpret_cast<const f32x4*>(xp + 8 * q);
+    if (hp) hr[q] = *reinterpret_cast<const f32x4*>(hp + 8 * q);
+  }
+  float rn = 0.f;
+  static_assert((4 * NKB) % P == 0, "ring slots must not depend on the feature block");
+#pragma unroll(NDB > 8 ? 1 : NDB)  // wide D: keep the feature-block loop rolled (registers)
   for (int ib = 0; ib < NDB; ++ib) {
     f32x16 rb;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 t = *reinterpret_cast<const f32x4*>(xp + ib * 32 + 8 * q);
+      f32x4 t = xr[q];
       if (hp) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(hp + ib * 32 + 8 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = __fsub_rn(t[e], u[e]);
+        for (int e = 0; e < 4; ++e) t[e] = __fsub_rn(t[e], hr[q][e]);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -178,16 +193,28 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
         rn = fmaf(t[e], t[e], rn);
       }
     }
+    if (ib + 1 < NDB) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xr[q] = *reinterpret_cast<const f32x4*>(xp + (ib + 1) * 32 + 8 * q);
+        if (hp) hr[q] = *reinterpret_cast<const f32x4*>(hp + (ib + 1) * 32 + 8 * q);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int cb = 0; cb < NKB; ++cb) {
-        const f32x4 w = wp[((cb * NDB + ib) * 4 + q) * 64];
+        const int i = (ib * 4 + q) * NKB + cb;
+        const f32x4 w = ring[(q * NKB + cb) % P];
+        ring[(q * NKB + cb) % P] = wp[frag_ofs(i + P)];  // past the end: inside the 16-fragment padding of the stream
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], rb[4 * q + e], acc[cb], 0, 0, 0);
       }
   }
+  static_assert(NFR > 0, "");
   rn += __shfl_xor(rn, 32);
   float* mytab = table + wave * 32 * LDK;
   float* row = mytab + j * LDK;
@@ -224,8 +251,7 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
           bi[u] = take ? k : bi[u];
         }
       }
-#pragma unroll
-      for (int u = 0; u < GP; ++u) wave_argmin(bv[u], bi[u]);  // GP independent VALU chains
+      wave_argmin_n<GP>(bv, bi);  // GP interleaved value chains, one tie branch
 #pragma unroll
       for (int u = 0; u < GP; ++u) {
         if (gl0 + u < gend) {

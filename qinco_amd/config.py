@@ -112,6 +112,9 @@ BASELINE_CONFIGS = {
     # IVF-qinco2 models of the reference's large-scale search (README "IVF-qinco2_*"), ivf_K = 2^20
     "IVF_L": preset("qinco2-L", D=128, M=8, B=8, ivf_K=1 << 20),
     "IVF_S": preset("qinco2-S", D=128, M=8, B=8, ivf_K=1 << 20),
+    # the smaller presets of the reference (config/model_args/qinco2-S.yaml, qinco2-M.yaml) on BigANN-shaped data
+    "S": preset("qinco2-S", D=128, M=8, B=8),
+    "M": preset("qinco2-M", D=128, M=8, B=8),
     # QINCo1 on 768-d data (De = D = 768): the 16-row tile kernel (csrc/mlp16_kernel.hpp)
     "Q1_768": preset("qinco1", D=768, M=8),
 }

@@ -16,7 +16,8 @@
 //
 // Kernel shape (passes A and B share it): a wave keeps VS x 32 vectors as fp16 B operands (VS = 2 for D <= 256), streams
 // 1 KiB centroid fragments (32 centroids x 16 features of fp16) through a fenced register ring, and reduces each 32 x 32
-// tile on the VALU: 2 instructions per (vector, centroid) pair in pass A, 2 + a rare slow path in pass B.
+// tile on the VALU: ONE instruction per (vector, centroid) pair (the accumulators start at -|c|^2/2), plus a rare slow
+// path in pass B.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -55,7 +56,7 @@ template <int D, int MODE>
 __global__ void __launch_bounds__(256)
 ivf_f16_kernel(IvfF16Args a) {
   constexpr int NK = D / 16;                 // k-steps (fragments) per block of 32 centroids
-  constexpr int VS = D <= 256 ? 2 : 1;       // sets of 32 vectors per wave
+  constexpr int VS = D <= 256 ? 2 : 1;       // sets of 32 vectors per wave (4 sets: pass A -12 %, pass B +34 %)
   constexpr int P = NK >= 8 ? 8 : NK;        // ring depth in fragments (divides NK for every supported D)
   static_assert(NK % P == 0, "ring depth must divide the fragments per block");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -89,7 +90,7 @@ ivf_f16_kernel(IvfF16Args a) {
     }
     xn += __shfl_xor(xn, 32);
     amax = fmaxf(amax, __shfl_xor(amax, 32));
-    mn[s] = __builtin_inff();
+    mn[s] = 0.f;
     thr[s] = 0.f;
     if constexpr (MODE == 1) {
       const float xnorm = sqrtf(xn) * 1.000001f;
@@ -111,15 +112,29 @@ ivf_f16_kernel(IvfF16Args a) {
 #pragma unroll
   for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
 
+  // The accumulators start at -|c|^2/2, so the tile comes out as  -s~ = x~.c~ - |c|^2/2  and the epilogue is ONE VALU
+  // instruction per (vector, centroid) pair (v_max in pass A, v_cmp in pass B) instead of subtract + min.  The
+  // centroid norms of the next block are fetched during the current one.
+  f32x4 cn[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) cn[g] = *reinterpret_cast<const f32x4*>(a.cnorm_half + cb0 * 32 + 8 * g + 4 * half);
+  float nthr[VS];
+#pragma unroll
+  for (int s = 0; s < VS; ++s) {
+    nthr[s] = -thr[s];
+    mn[s] = -__builtin_inff();  // running maximum of -s~
+  }
   auto block = [&](const int cb) __attribute__((always_inline)) {
     f32x16 acc[VS];
 #pragma unroll
     for (int s = 0; s < VS; ++s)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[s][i] = 0.f;
-    f32x4 cn[4];  // fetched ahead of the MFMAs
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) cn[g] = *reinterpret_cast<const f32x4*>(a.cnorm_half + cb * 32 + 8 * g + 4 * half);
+        for (int e = 0; e < 4; ++e) acc[s][4 * g + e] = -cn[g][e];
+    const int cbn = cb + 1 < a.nblocks ? cb + 1 : cb;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) cn[g] = *reinterpret_cast<const f32x4*>(a.cnorm_half + cbn * 32 + 8 * g + 4 * half);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
       const h16x8 w = ring[k % P];
@@ -135,17 +150,13 @@ ivf_f16_kernel(IvfF16Args a) {
 #pragma unroll
       for (int s = 0; s < VS; ++s)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) mn[s] = fminf(mn[s], cn[g][e] - acc[s][4 * g + e]);
+        for (int i = 0; i < 16; ++i) mn[s] = fmaxf(mn[s], acc[s][i]);
     } else {
       bool any = false;
 #pragma unroll
       for (int s = 0; s < VS; ++s)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) any |= (cn[g][e] - acc[s][4 * g + e]) <= thr[s];
+        for (int i = 0; i < 16; ++i) any |= acc[s][i] >= nthr[s];
       if (__builtin_expect(__any(any), 0)) {  // rare: about one hit per vector in ivf_K centroids
 #pragma unroll
         for (int s = 0; s < VS; ++s)
@@ -153,7 +164,7 @@ ivf_f16_kernel(IvfF16Args a) {
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (valid[s] && (cn[g][e] - acc[s][4 * g + e]) <= thr[s]) {
+              if (valid[s] && acc[s][4 * g + e] >= nthr[s]) {
                 const int pos = atomicAdd(a.cand_count, 1);
                 if (pos < a.cand_cap) {
                   a.cand_vec[pos] = (int)vec[s];
@@ -177,7 +188,7 @@ ivf_f16_kernel(IvfF16Args a) {
   if constexpr (MODE == 0) {
 #pragma unroll
     for (int s = 0; s < VS; ++s) {
-      float m = fminf(mn[s], __shfl_xor(mn[s], 32));
+      const float m = -fmaxf(mn[s], __shfl_xor(mn[s], 32));  // min of s~
       if (valid[s] && half == 0) atomicMin(a.approx_min + vec[s], f32_ordered(m));
     }
   }

@@ -8,5 +8,5 @@ timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_IN
 timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace -d $O/prof_ivf2 -o pmc -- python $R/scripts/bench_extra.py IVF_S --beams 8 --steps 1 > $O/prof_ivf2.log 2>&1
 cd $R
 python scripts/rocpd_summary.py $O/prof_ivf0/trace_results.db $O/ivf_trace && head -8 $O/ivf_trace_kernel_stats.csv | cut -c1-200
-python scripts/rocpd_summary.py $O/prof_ivf/pmc_results.db $O/ivf_pmc && grep "ivf_assign\|^kernel" $O/ivf_pmc_counters.csv | cut -c1-400
-python scripts/rocpd_summary.py $O/prof_ivf2/pmc_results.db $O/ivf_pmc2 && grep "ivf_assign\|^kernel" $O/ivf_pmc2_counters.csv | cut -c1-400
+python scripts/rocpd_summary.py $O/prof_ivf/pmc_results.db $O/ivf_pmc && grep "ivf_\|^kernel" $O/ivf_pmc_counters.csv | cut -c1-400
+python scripts/rocpd_summary.py $O/prof_ivf2/pmc_results.db $O/ivf_pmc2 && grep "ivf_\|^kernel" $O/ivf_pmc2_counters.csv | cut -c1-400

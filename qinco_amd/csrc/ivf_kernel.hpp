@@ -143,14 +143,17 @@ template <int D, int NKB>
 __global__ void __launch_bounds__(256)
 dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xhat, int F,
                       const f32x4* __restrict__ cstream, const float* __restrict__ cnorm, long G, int T,
-                      int* __restrict__ ids_out) {
+                      int* __restrict__ ids_out, int gpw) {
+  // gpw = groups per wave (32, or 8 for small launches: the T selection rounds of a wave's groups are serial, so a
+  // launch that cannot fill the chip with 32-group waves is latency-bound -- 200 us for 8192 groups; lanes past gpw
+  // repeat the last group in the MFMA tile and are not selected)
   constexpr int NDB = D / 32, K = NKB * 32, LDK = K + 4;
   __shared__ __attribute__((aligned(16))) float table[4 * 32 * LDK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
-  const long g0 = ((long)blockIdx.x * 4 + wave) * 32;
+  const long g0 = ((long)blockIdx.x * 4 + wave) * gpw;
   if (g0 >= G) return;  // wave-uniform; only wave-level ordering below
-  long g = g0 + j;
+  long g = g0 + (j < gpw ? j : gpw - 1);
   if (g >= G) g = G - 1;
   const float* xp = x + (g / F) * D + half * 4;
   const float* hp = xhat ? xhat + g * D + half * 4 : nullptr;
@@ -233,7 +236,7 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
   // Selection: the T rounds of one group are a chain of dependent cross-lane shuffles (latency-bound), so GP
   // groups are reduced side by side to give the scheduler independent chains to interleave.
   constexpr int GP = 4;
-  const int gend = (int)((G - g0) < 32 ? (G - g0) : 32);
+  const int gend = (int)((G - g0) < gpw ? (G - g0) : gpw);
   for (int gl0 = 0; gl0 < gend; gl0 += GP) {
     for (int t = 0; t < T; ++t) {
       float bv[GP];

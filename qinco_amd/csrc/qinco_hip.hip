@@ -668,8 +668,9 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st) {
 template <int D>
 static void launch_table_inst(const float* x, const float* xhat, int F, const f32x4* cs, const float* cn, long G, int T,
                               int* ids, hipStream_t st) {
-  hipLaunchKernelGGL((dist_topk_mfma_kernel<D, 8>), dim3((unsigned)((G + 127) / 128)), dim3(256), 0, st, x, xhat, F, cs, cn,
-                     G, T, ids);
+  const int gpw = G <= 16384 ? 8 : 32;  // small launches: 8 groups per wave (selection latency, see the kernel)
+  hipLaunchKernelGGL((dist_topk_mfma_kernel<D, 8>), dim3((unsigned)((G + 4 * gpw - 1) / (4 * gpw))), dim3(256), 0, st, x, xhat,
+                     F, cs, cn, G, T, ids, gpw);
 }
 
 static int launch_dist_topk(qinco_handle_s* h, const float* x, const float* xhat, int F, const float* cb,

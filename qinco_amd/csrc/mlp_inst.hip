@@ -11,7 +11,9 @@
 // registers per lane), but with small models the 16-row kernel fits 3 workgroups per CU, and then single waves read
 // wrong weight fragments now and then (about 1 wave in 100 at 1500 workgroups; deterministic and exact with one
 // workgroup per CU; fully conservative waits -- vmcnt(0) + lgkmcnt(0) before every ring barrier -- do not cure it, so
-// it is not the ring's landing / overwrite protocol).  Root cause not identified; the padding costs nothing.
+// it is not the ring's landing / overwrite protocol; waiting for one more landed group than the protocol needs does not
+// cure it either, so it is not a lag between vmcnt and LDS visibility).  Root cause not identified; the padding costs
+// nothing.
 static constexpr unsigned kExclusiveLds = (QVAR & 64) ? 36u * 1024u : 0u;  // shared ring: 48 KiB static + 36 = 84 > 80
 
 extern "C" __attribute__((visibility("hidden")))

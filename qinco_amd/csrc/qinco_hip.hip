@@ -93,6 +93,7 @@ struct qinco_handle_s {
   f32x4* ivf_stream = nullptr;      // centroids packed as MFMA A-operand fragments
   unsigned long long* ivf_best = nullptr;  // (max_batch) merged (distance, id) keys
   // fp16-filter passes of the IVF assignment (ivf_f16_kernel.hpp)
+  bool table_valu = false;          // QINCO_TABLE_VALU=1 at create: VALU pre-selection table kernel (A/B)
   bool ivf_f16 = false;
   void* ivf_h16 = nullptr;           // centroids as fp16 MFMA fragments
   float* ivf_cnorm_half = nullptr;   // |c|^2 / 2
@@ -486,6 +487,7 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   h->B = d.B;
   h->inst = fn;
   h->std_ = w->data_std;
+  h->table_valu = getenv("QINCO_TABLE_VALU") != nullptr;
   const int kRing = fn ? fn->P : 8;
   if (fn && (fn->var & 32) && d.L == 0) {  // FOLD2 peels FFN block 0: a model without FFN blocks takes the plain FOLD kernel
     fn = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~32);
@@ -676,7 +678,7 @@ static void launch_table_inst(const float* x, const float* xhat, int F, const f3
 static int launch_dist_topk(qinco_handle_s* h, const float* x, const float* xhat, int F, const float* cb,
                             const f32x4* cstream, const float* cn, long G, int T, int* ids, hipStream_t st) {
   const qinco_desc& d = h->d;
-  if (cstream && !getenv("QINCO_TABLE_VALU")) {
+  if (cstream && !h->table_valu) {
     switch (d.D) {
       case 32: launch_table_inst<32>(x, xhat, F, cstream, cn, G, T, ids, st); break;
       case 96: launch_table_inst<96>(x, xhat, F, cstream, cn, G, T, ids, st); break;

@@ -235,7 +235,7 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
   __builtin_amdgcn_wave_barrier();
   // Selection: the T rounds of one group are a chain of dependent cross-lane shuffles (latency-bound), so GP
   // groups are reduced side by side to give the scheduler independent chains to interleave.
-  constexpr int GP = 4;
+  constexpr int GP = 8;
   const int gend = (int)((G - g0) < gpw ? (G - g0) : gpw);
   for (int gl0 = 0; gl0 < gend; gl0 += GP) {
     for (int t = 0; t < T; ++t) {

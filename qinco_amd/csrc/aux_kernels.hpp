@@ -13,118 +13,64 @@ namespace qinco {
 // Lexicographic (value, index) minimum across the 64 lanes of a wave, result in every lane (ties -> lower index,
 // which is what argmin returns on the reference CPU path; topk's order among exact ties is unspecified).
 // All on the VALU: DPP lane permutes inside the 16-lane rows, gfx950's v_permlane16_swap / v_permlane32_swap across
-// rows.  (__shfl_xor is ds_bpermute_b32: an LDS-crossbar round trip per level; the T-round selections were bound by
-// exactly that latency.)  Needs all 64 lanes active.
+// rows.  (__shfl_xor is ds_bpermute_b32: an LDS-crossbar round trip per level; a float (value, index) compare-select
+// per level and a ballot / v_readlane fast path were both slower than the integer form below: SGPR round trips.)
+// Branch-free, SGPR-free: reduce the order-preserving integer image of the value with v_min_u32 (fused with the DPP
+// permute: one instruction per level), then reduce the index among the lanes that hold the minimum the same way.
+// Exactly the lexicographic (value, index) minimum (-0.0 is folded into +0.0 first, as a float compare treats it).
+// Needs all 64 lanes active.
 template <int CTRL>
-QINCO_DEV float dpp_f(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+QINCO_DEV unsigned dpp_u(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
 }
-template <int CTRL>
-QINCO_DEV int dpp_i(int x) {
-  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false);
-}
-QINCO_DEV void lexmin(float& v, int& i, float ov, int oi) {
-  const bool take = (ov < v) || (ov == v && oi < i);
-  v = take ? ov : v;
-  i = take ? oi : i;
-}
-QINCO_DEV void wave_argmin_lex(float& v, int& i) {
-  lexmin(v, i, dpp_f<0xB1>(v), dpp_i<0xB1>(i));    // quad_perm [1,0,3,2]: lane ^ 1
-  lexmin(v, i, dpp_f<0x4E>(v), dpp_i<0x4E>(i));    // quad_perm [2,3,0,1]: lane ^ 2
-  lexmin(v, i, dpp_f<0x141>(v), dpp_i<0x141>(i));  // row_half_mirror: pairs the two quads of each 8 lanes
-  lexmin(v, i, dpp_f<0x140>(v), dpp_i<0x140>(i));  // row_mirror: pairs the two halves of each row
-  {  // rows 0<->1 and 2<->3: after the swap one result holds the even row's value, the other the odd row's
-    const unsigned vb = __builtin_bit_cast(unsigned, v), ib = (unsigned)i;
-    const auto rv = __builtin_amdgcn_permlane16_swap(vb, vb, false, false);
-    const auto ri = __builtin_amdgcn_permlane16_swap(ib, ib, false, false);
-    v = __builtin_bit_cast(float, (unsigned)rv[0]);
-    i = (int)ri[0];
-    lexmin(v, i, __builtin_bit_cast(float, (unsigned)rv[1]), (int)ri[1]);
-  }
-  {  // lower 32 lanes <-> upper 32 lanes
-    const unsigned vb = __builtin_bit_cast(unsigned, v), ib = (unsigned)i;
-    const auto rv = __builtin_amdgcn_permlane32_swap(vb, vb, false, false);
-    const auto ri = __builtin_amdgcn_permlane32_swap(ib, ib, false, false);
-    v = __builtin_bit_cast(float, (unsigned)rv[0]);
-    i = (int)ri[0];
-    lexmin(v, i, __builtin_bit_cast(float, (unsigned)rv[1]), (int)ri[1]);
-  }
-}
-
-// The same result with a third of the instructions in the common case: reduce the VALUE alone (one v_min per level),
-// then look at which lanes hold it.  One lane: its index is the answer (v_readlane).  Several lanes (exact ties, rare):
-// fall back to the lexicographic reduction so that the lowest index wins.  The branch is wave-uniform.
-QINCO_DEV void wave_argmin(float& v, int& i) {
-  float m = v;
-  m = fminf(m, dpp_f<0xB1>(m));
-  m = fminf(m, dpp_f<0x4E>(m));
-  m = fminf(m, dpp_f<0x141>(m));
-  m = fminf(m, dpp_f<0x140>(m));
+QINCO_DEV unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
+QINCO_DEV unsigned wave_umin(unsigned k) {
+  k = umin(k, dpp_u<0xB1>(k));
+  k = umin(k, dpp_u<0x4E>(k));
+  k = umin(k, dpp_u<0x141>(k));
+  k = umin(k, dpp_u<0x140>(k));
   {
-    const unsigned mb = __builtin_bit_cast(unsigned, m);
-    const auto r = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
-    m = fminf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    const auto r = __builtin_amdgcn_permlane16_swap(k, k, false, false);
+    k = umin((unsigned)r[0], (unsigned)r[1]);
   }
   {
-    const unsigned mb = __builtin_bit_cast(unsigned, m);
-    const auto r = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-    m = fminf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    const auto r = __builtin_amdgcn_permlane32_swap(k, k, false, false);
+    k = umin((unsigned)r[0], (unsigned)r[1]);
   }
-  const unsigned long long holders = __ballot(v == m);
-  if (__popcll(holders) == 1) {
-    i = __builtin_amdgcn_readlane(i, __ffsll((long long)holders) - 1);
-    v = m;
-  } else {
-    wave_argmin_lex(v, i);
-  }
+  return k;
 }
-
-// N independent reductions side by side: the N value chains interleave (each level of one chain waits on the
-// previous one), and the tie test is ONE wave-uniform branch for all N instead of a branch per reduction -- a branch
-// after every reduction serialised them (rocprofv3: ~850 cycles per reduction in dist_topk_mfma_kernel).
-QINCO_DEV float min_nn(float a, float b) { return b < a ? b : a; }   // no NaN canonicalisation (v_cmp + v_cndmask)
+QINCO_DEV unsigned ordered_bits(float d) {
+  const unsigned u = __builtin_bit_cast(unsigned, d + 0.f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+QINCO_DEV float from_ordered_bits(unsigned u) {
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __builtin_bit_cast(float, u);
+}
 template <int N>
-QINCO_DEV void wave_argmin_n(float (&v)[N], int (&i)[N]) {
-  float m[N];
+QINCO_DEV void wave_argmin_u(float (&v)[N], int (&i)[N]) {
+  unsigned key[N], m[N], c[N];
 #pragma unroll
-  for (int u = 0; u < N; ++u) m[u] = v[u];
+  for (int u = 0; u < N; ++u) key[u] = ordered_bits(v[u]);
 #pragma unroll
-  for (int u = 0; u < N; ++u) m[u] = min_nn(m[u], dpp_f<0xB1>(m[u]));
+  for (int u = 0; u < N; ++u) m[u] = wave_umin(key[u]);
 #pragma unroll
-  for (int u = 0; u < N; ++u) m[u] = min_nn(m[u], dpp_f<0x4E>(m[u]));
+  for (int u = 0; u < N; ++u) c[u] = key[u] == m[u] ? (unsigned)i[u] : 0x7fffffffu;
 #pragma unroll
-  for (int u = 0; u < N; ++u) m[u] = min_nn(m[u], dpp_f<0x141>(m[u]));
-#pragma unroll
-  for (int u = 0; u < N; ++u) m[u] = min_nn(m[u], dpp_f<0x140>(m[u]));
+  for (int u = 0; u < N; ++u) c[u] = wave_umin(c[u]);
 #pragma unroll
   for (int u = 0; u < N; ++u) {
-    const unsigned mb = __builtin_bit_cast(unsigned, m[u]);
-    const auto r = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
-    m[u] = min_nn(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    v[u] = from_ordered_bits(m[u]);
+    i[u] = (int)c[u];
   }
-#pragma unroll
-  for (int u = 0; u < N; ++u) {
-    const unsigned mb = __builtin_bit_cast(unsigned, m[u]);
-    const auto r = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-    m[u] = min_nn(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
-  }
-  unsigned long long holders[N];
-  bool unique = true;
-#pragma unroll
-  for (int u = 0; u < N; ++u) {
-    holders[u] = __ballot(v[u] == m[u]);
-    unique &= __popcll(holders[u]) == 1;
-  }
-  if (unique) {
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-      i[u] = __builtin_amdgcn_readlane(i[u], __ffsll((long long)holders[u]) - 1);
-      v[u] = m[u];
-    }
-  } else {  // exact ties somewhere (or no finite value left): lexicographic, lowest index wins
-#pragma unroll
-    for (int u = 0; u < N; ++u) wave_argmin_lex(v[u], i[u]);
-  }
+}
+
+QINCO_DEV void wave_argmin(float& v, int& i) {
+  float a[1] = {v};
+  int b[1] = {i};
+  wave_argmin_u<1>(a, b);
+  v = a[0];
+  i = b[0];
 }
 
 // ---------------------------------------------------------------------------------------------

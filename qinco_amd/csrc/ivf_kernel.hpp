@@ -180,7 +180,8 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
   }
   float rn = 0.f;
   static_assert((4 * NKB) % P == 0, "ring slots must not depend on the feature block");
-#pragma unroll(NDB > 8 ? 1 : NDB)  // wide D: keep the feature-block loop rolled (registers)
+  constexpr int IB_UNROLL = NDB > 8 ? 1 : NDB;  // wide D: keep the feature-block loop rolled (registers)
+#pragma unroll IB_UNROLL
   for (int ib = 0; ib < NDB; ++ib) {
     f32x16 rb;
 #pragma unroll
@@ -254,7 +255,7 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
           bi[u] = take ? k : bi[u];
         }
       }
-      wave_argmin_n<GP>(bv, bi);  // GP interleaved value chains, one tie branch
+      wave_argmin_u<GP>(bv, bi);  // GP interleaved integer-min chains: no branch, no SGPR round trip
 #pragma unroll
       for (int u = 0; u < GP; ++u) {
         if (gl0 + u < gend) {

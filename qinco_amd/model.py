@@ -3,7 +3,7 @@
 `QINCoHIP` exposes the surface that qinco_tasks / search_tasks use on a QINCo / QINCoInferenceWrapper
 (SURVEY.md 8b): model(x, step="encode") -> (M, N) int64, model(codes, step="decode") -> (N, D) float32,
 .encode(x_norm) -> (codes_MB, xhat_BD), .decode(codes_MB), .built / .build(), .load_state_dict(sd), .eval(),
-.to(device), .data_mean / .data_std, get_codebooks_refs().  All arithmetic runs in libqinco_hip (HIP, gfx950);
+.to(device), .data_mean / .data_std, get_codebooks_refs(), .qinco_model.steps[0].ivf_centroids.weight.  All arithmetic runs in libqinco_hip (HIP, gfx950);
 there is no CPU implementation behind this class.
 """
 from __future__ import annotations
@@ -51,6 +51,28 @@ class QINCoHIP:
         self.data_mean = self._sd["data_mean"]
         self.data_std = self._sd["data_std"]
         self.built = True
+
+    @property
+    def qinco_model(self):
+        """The inner-model attribute path the IVF search reads (search_tasks.py:449):
+        `model.qinco_model.steps[0].ivf_centroids.weight` (and `.steps[m].codebook.weight`), as read-only arrays
+        (torch tensors when torch is importable, like the reference's parameters)."""
+        from types import SimpleNamespace as NS
+
+        def wrap(a):
+            try:
+                import torch
+                return torch.from_numpy(np.ascontiguousarray(a))
+            except ImportError:  # pragma: no cover
+                return a
+        steps = []
+        for m in range(self.cfg.M_total):
+            st = NS(codebook=NS(weight=wrap(self._sd[f"steps.{m}.codebook.weight"]))) if (
+                f"steps.{m}.codebook.weight" in self._sd) else NS()
+            if m == 0 and self.cfg.ivf:
+                st.ivf_centroids = NS(weight=wrap(self._sd["steps.0.ivf_centroids.weight"]))
+            steps.append(st)
+        return NS(steps=steps)
 
     def eval(self):
         return self

@@ -384,3 +384,16 @@ def test_ivf_fp16_filter_falls_back_on_ties_and_range(monkeypatch):
     assert np.array_equal(got2, eng3.encode(xbig)[:, 0])
     eng2.close()
     eng3.close()
+
+
+def test_model_exposes_inner_model_attribute_path():
+    """search_tasks.py:449 reads model.qinco_model.steps[0].ivf_centroids.weight on the inference wrapper."""
+    from qinco_amd import synth_state_dict
+    from qinco_amd.model import QINCoHIP
+    cfg, seed = golden_cases()["tiny_ivf_beam"]
+    sd = synth_state_dict(cfg, seed)
+    model = QINCoHIP(cfg, sd, max_batch=64)
+    w = model.qinco_model.steps[0].ivf_centroids.weight
+    assert tuple(w.shape) == (cfg.ivf_K, cfg.D) and np.array_equal(np.asarray(w), sd["steps.0.ivf_centroids.weight"])
+    assert np.array_equal(np.asarray(model.qinco_model.steps[1].codebook.weight), sd["steps.1.codebook.weight"])
+    assert len(model.get_codebooks_refs()) == cfg.M

@@ -56,15 +56,13 @@ class QINCoHIP:
     def qinco_model(self):
         """The inner-model attribute path the IVF search reads (search_tasks.py:449):
         `model.qinco_model.steps[0].ivf_centroids.weight` (and `.steps[m].codebook.weight`), as read-only arrays
-        (torch tensors when torch is importable, like the reference's parameters)."""
+        (torch tensors when the process has imported torch, like the reference's parameters)."""
         from types import SimpleNamespace as NS
 
         def wrap(a):
-            try:
-                import torch
-                return torch.from_numpy(np.ascontiguousarray(a))
-            except ImportError:  # pragma: no cover
-                return a
+            import sys
+            torch = sys.modules.get("torch")   # a tensor for torch users, without importing torch for the others
+            return torch.from_numpy(np.ascontiguousarray(a)) if torch is not None else a
         steps = []
         for m in range(self.cfg.M_total):
             st = NS(codebook=NS(weight=wrap(self._sd[f"steps.{m}.codebook.weight"]))) if (

@@ -2,25 +2,39 @@
 """bench.py -- encode throughput of the MI355X QINCo2 engine on BASELINE.json's metric.
 
     python bench.py [--gpus N --steps K --warmup W] [--workload C2] [--batch 16384]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-A "step" = one pass of the hot path (model(x, step="encode")) over one batch of `--batch` synthetic fp32
-vectors per GPU, inputs already resident in HBM.  Weak scaling: every rank encodes its own shard of the
-database (contiguous range sharding like search_tasks.py:103-104, no data-path collective); the uint8 codes
-of all timed steps are gathered to rank 0 over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+`--gpus N` with N > 1 works both ways: pre-launched (the driver's `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) and from a bare `python bench.py --gpus N`, which re-executes itself under torch.distributed.run with one
+rank per GPU (like the reference's `accelerate launch --multi_gpu`, run.sh:8).
+
+A "step" = one pass of the hot path (model(x, step="encode")) over one batch of `--batch` synthetic fp32 vectors per
+GPU.  Every step (and every warm-up step) encodes a DIFFERENT batch; all batches are generated on the device before the
+timed region (inputs resident in HBM).  Weak scaling: every rank encodes its own shard of the synthetic database
+(contiguous range sharding like search_tasks.py:103-104, no data-path collective); the uint8 codes of all timed steps are
+gathered to rank 0 over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
 
 metric/unit: encode vectors/s (BASELINE.json "metric"); workload C2 = qinco2-L 8x8, D=128, A=16, B=8
 (BASELINE.json configs[1]) with seeded synthetic weights (no trained checkpoints offline).
-roofline: the fused codeword-MLP kernel (99.9 % of the FLOPs), fp32 MFMA bound: achieved = algorithmic FLOPs
-per launch (rows x R_mlp) / mean launch duration measured with HIP events on the launch stream.
-cpu_baseline: the numpy oracle (oracle/qinco_oracle.py, shown equal to the imported reference in
-tests/golden) timed on this box's host cores on a bounded sample.
+roofline: the fused codeword-MLP kernel (99.9 % of the FLOPs), fp32 MFMA bound.  `achieved` = ALGORITHMIC FLOPs per
+launch (rows x R_mlp) / mean launch duration measured with HIP events on the launch stream; `frac` =
+achieved / peak.  The kernel folds the row-independent head of the MLP out, so the matrix pipe executes
+fewer FLOPs than the algorithm counts: `frac_executed` = executed FLOPs / duration / peak is the pipe-utilisation figure
+(it cannot exceed 1; the algorithmic one can on short models).
+Also in the line (N = 1, measured after the timed region): `decode` (vectors/s + its roofline), `mse` of
+encode -> decode over the timed batches (AnyVectMSE, metrics.py:51-58), `beam1` (greedy encode), `batch_1024` (encode at
+the reference's default batch, qinco_cfg.yaml:38).
+cpu_baseline: the oracle restatement with its codeword MLP on torch CPU ops (oracle/qinco_oracle.py, backend "torch":
+same op sequence as the reference's CPU path, codes equal to the numpy oracle and to the imported reference) timed on
+this box's host cores at the reference's batch of 1024 on a bounded sample.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -31,31 +45,34 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+# measured in the build container (8 cores, C2, 256 vectors): imported reference wrapper 46.5 vec/s,
+# this port (torch backend) 42.3 vec/s, numpy oracle 9.3 vec/s -- all three give identical codes
+REF_OVER_PORT_CONTAINER = 1.10
 
 
 def pmc_traffic_per_row():
     """L2<->fabric bytes per MLP row from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE; profiles/r01_c2_traffic.json).  Counters cannot be read from inside this process, so the figure
-    of the separate PMC run of this same command is scaled to this run's rows per launch."""
-    try:
-        with open(ROOT / "profiles" / "r01_c2_traffic.json") as f:
-            return float(json.load(f)["bytes_per_row"])
-    except Exception:
-        return None
+    WRITE_SIZE).  Counters cannot be read from inside this process, so the figure of the separate PMC run of this
+    same command is scaled to this run's rows per launch."""
+    for name in ("r02_c2_traffic.json", "r01_c2_traffic.json"):
+        try:
+            with open(ROOT / "profiles" / name) as f:
+                return float(json.load(f)["bytes_per_row"]), name
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(cfg, sd, budget_s: float = 12.0, chunk: int = 32):
-    """Oracle encode throughput on the host cores (rank 0, N=1 only): bounded sample of the same workload."""
+def cpu_baseline(cfg, sd, budget_s: float = 20.0, chunk: int = 1024):
+    """Oracle encode throughput on the host cores (rank 0, N=1 only): bounded sample of the same workload at the
+    reference's default batch (qinco_cfg.yaml:38), ATen threads = the cores torch picked (stated)."""
+    import torch
     from oracle.qinco_oracle import OracleQINCo
     from qinco_amd import synth_vectors
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    oracle = OracleQINCo.from_config(cfg, sd)
-    x = synth_vectors(cfg, sd, 4096, seed=4242)
-    oracle(x[:8], step="encode")  # warm-up
+    threads = int(torch.get_num_threads())
+    oracle = OracleQINCo.from_config(cfg, sd, backend="torch")
+    x = synth_vectors(cfg, sd, 16 * chunk, seed=4242)
+    oracle(x[:64], step="encode")  # warm-up
     done, t0 = 0, time.perf_counter()
     while done < len(x):
         oracle(x[done:done + chunk], step="encode")
@@ -63,8 +80,37 @@ def cpu_baseline(cfg, sd, budget_s: float = 12.0, chunk: int = 32):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "vectors/s", "cores": int(threads), "kind": "port",
-            "sample": f"{done} vectors of the same workload in {dt:.1f} s (numpy fp32 oracle, batches of {chunk})"}
+    v = done / dt
+    return {"value": v, "unit": "vectors/s", "cores": threads, "threads": threads, "kind": "port",
+            "gflops": v * cfg.encode_flops_per_vector() / 1e9,
+            "reference_over_port_in_build_container": REF_OVER_PORT_CONTAINER,
+            "sample": f"{done} vectors of the same workload in {dt:.1f} s (oracle restatement, codeword MLP on torch CPU "
+                      f"fp32 ops, batches of {chunk}, {threads} ATen threads of {os.cpu_count()} logical cores)"}
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n: int) -> int:
+    """A bare `python bench.py --gpus N`: re-execute under torch.distributed.run, one rank per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def synth_batch_device(torch, cfg, mean_t, std, n, seed, dev):
+    """x = mean + std * N(0, I) (the S0 inputs of SURVEY.md 8d), drawn on the device from a seeded generator."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    z = torch.randn((n, cfg.D), generator=g, device=dev, dtype=torch.float32)
+    return z * std + mean_t
 
 
 def main():
@@ -75,9 +121,13 @@ def main():
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4"])
     ap.add_argument("--batch", type=int, default=16384, help="vectors per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the decode / mse / beam1 / batch_1024 legs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank). gloo is a test hook: ranks may share a GPU.")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -86,12 +136,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run `python bench.py --gpus N` bare)")
     ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU (qinco_amd has no CPU path)")
     if args.backend == "nccl" and world > ndev:
-        raise SystemExit(f"{world} ranks but only {ndev} GPU(s): RCCL needs one GPU per rank")
-    dev_index = local_rank % max(ndev, 1)
+        raise SystemExit(f"{world} ranks but only {ndev} GPU(s): RCCL needs one GPU per rank (--backend gloo lets ranks share one)")
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -102,17 +153,21 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
-    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    from qinco_amd import QincoEngine, synth_state_dict
     from qinco_amd.config import BASELINE_CONFIGS
+    from qinco_amd.evaluate import sqerr_sum
 
     cfg = BASELINE_CONFIGS[args.workload]
     sd = synth_state_dict(cfg, 1236)
     eng = QincoEngine(cfg, sd, max_batch=args.batch)
+    K, W = args.steps, args.warmup
 
-    # this rank's shard of the synthetic database: rows [rank*batch, (rank+1)*batch) of one seeded stream per step
-    x_host = synth_vectors(cfg, sd, args.batch, seed=42 + rank)
-    x = torch.from_numpy(x_host).to(dev)
-    K = args.steps
+    # This rank's shard of the synthetic database: step s of rank r encodes rows [(r (W + K) + s) batch, ... + batch) of one
+    # seeded stream; every batch is distinct and resident in HBM before the clock starts.
+    mean_t = torch.from_numpy(np.asarray(sd["data_mean"])).to(dev)
+    std = float(sd["data_std"])
+    batches = [synth_batch_device(torch, cfg, mean_t, std, args.batch, 1_000_003 * (rank * (W + K) + s) + 42, dev)
+               for s in range(W + K)]
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -123,68 +178,142 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        eng.encode(x, code_dtype=np.uint8)
+    for s in range(W):
+        eng.encode(batches[s], code_dtype=np.uint8)
     barrier()
     eng.profile_enable(True)
     eng.profile_read()
     codes_steps = []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(K):
-        codes_steps.append(eng.encode(x, code_dtype=np.uint8))
+    for s in range(K):
+        codes_steps.append(eng.encode(batches[W + s], code_dtype=np.uint8))
     mine = torch.stack(codes_steps) if K else torch.empty(0, dtype=torch.uint8, device=dev)
+    t_enc = t_gather = 0.0
     if world > 1:  # the end-of-job gather of the uint8 codes over RCCL / xGMI
+        torch.cuda.synchronize(dev)
+        t_enc = time.perf_counter() - t0
         mine_c = mine.to(comm_dev)
         bucket = [torch.empty_like(mine_c) for _ in range(world)] if rank == 0 else None
         dist.gather(mine_c, bucket, dst=0)
         if rank == 0:
             assert len(bucket) == world and all(b.shape == mine_c.shape for b in bucket)
+        torch.cuda.synchronize(dev)
+        t_gather = time.perf_counter() - t0 - t_enc
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(False)
 
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine_t = torch.tensor([t_enc, t_gather], dtype=torch.float64, device=comm_dev)
+        allt = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(allt, mine_t)
+        per_rank = [[float(a[0]), float(a[1])] for a in allt]
 
     if rank == 0:
         total_vecs = K * args.batch * world
         value = total_vecs / dt if dt > 0 else 0.0
-        launches = max(prof["mlp_launches"], 1)
-        avg_ms = prof["mlp_ms"] / launches
-        flops_per_launch = prof["mlp_flops"] / launches
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        bpr = pmc_traffic_per_row() if args.workload == "C2" else None
-        rows_per_launch = flops_per_launch / cfg.mlp_flops_per_row()
-        # FOLD (mlp_kernel.hpp): the row-independent head of the MLP is not recomputed per row, so the MFMA executes
-        # fewer FLOPs than the reference's algorithm counts; `achieved` stays algorithmic, this is the executed share.
-        Ae = cfg.A or cfg.K
-        head = (2.0 * cfg.D * cfg.De if cfg.De != cfg.D else 0.0) + 2.0 * (cfg.De + cfg.D) * cfg.De   # FOLD
-        head += 2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0                                            # FOLD2
-        per_group = 2.0 * cfg.D * cfg.De + (2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0)               # xproj
-        executed = 1.0 - (head - per_group / Ae) / cfg.mlp_flops_per_row()
+        mlp_row = cfg.mlp_flops_per_row()
+
+        def mlp_roofline(pr):
+            launches = max(pr["mlp_launches"], 1)
+            avg_ms = pr["mlp_ms"] / launches
+            fpl = pr["mlp_flops"] / launches
+            ach = fpl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            return launches, avg_ms, fpl, ach
+
+        launches, avg_ms, flops_per_launch, achieved = mlp_roofline(prof)
+        bpr, bpr_src = pmc_traffic_per_row() if args.workload == "C2" else (None, None)
+        rows_per_launch = flops_per_launch / mlp_row
+        # FOLD / FOLD2 (mlp_kernel.hpp): the row-independent head of the MLP is not recomputed per row, so the MFMA
+        # executes fewer FLOPs than the reference's algorithm counts.
+        def executed_share(Ae):
+            head = (2.0 * cfg.D * cfg.De if cfg.De != cfg.D else 0.0) + 2.0 * (cfg.De + cfg.D) * cfg.De   # FOLD
+            head += 2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0                                            # FOLD2
+            per_group = 2.0 * cfg.D * cfg.De + (2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0)               # xproj
+            return 1.0 - (head - per_group / Ae) / mlp_row
+        executed = executed_share(cfg.A or cfg.K)
         out = {
             "metric": "encode vectors/sec (BigANN-shaped d=128 8x8, beam=%d)" % cfg.B,
-            "value": value, "unit": "vectors/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "value": value, "unit": "vectors/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3 if K else 0.0, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: qinco2-L 8x8 encode" if args.workload == "C2" else args.workload,
                        "D": cfg.D, "M": cfg.M, "K": cfg.K, "L": cfg.L, "de": cfg.De, "dh": cfg.dh, "A": cfg.A, "B": cfg.B,
                        "vectors_per_step_per_gpu": args.batch, "parallelism": f"shard{world}",
+                       "distinct_vectors_encoded": total_vecs,
+                       "inputs": "every step encodes a different seeded batch, all resident in HBM before the clock starts",
                        "weights": "seeded synthetic (RandomState 1236)",
                        "gflop_per_vector": eng.flops_per_vector("encode") / 1e9},
             "roofline": {"bound": "mfma", "kernel": "qinco::mlp_kernel (+ its xproj pre-GEMM)", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "frac_executed": achieved * executed / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": (bpr * rows_per_launch if bpr else None),
-                         "traffic_unit": "bytes per launch (L2<->fabric, PMC pass in profiles/r01_c2_traffic.json)",
+                         "traffic_unit": f"bytes per launch (L2<->fabric, PMC pass in profiles/{bpr_src})" if bpr else None,
                          "mfma_flops_executed_frac": executed, "mfma_pipe_tflops": achieved * executed,
                          "avg_launch_ms": avg_ms, "launches": prof["mlp_launches"],
                          "flops_per_launch": flops_per_launch,
                          "mlp_share_of_step_time": prof["mlp_ms"] * 1e-3 / dt if dt > 0 else None},
         }
+        if world > 1:
+            out["multi_gpu"] = {
+                "backend": args.backend,
+                "per_rank_encode_vectors_per_s": [K * args.batch / t[0] if t[0] > 0 else 0.0 for t in per_rank],
+                "per_rank_encode_s": [t[0] for t in per_rank],
+                "per_rank_gather_s": [t[1] for t in per_rank],
+                "gather_bytes_per_rank": int(mine.numel()),
+                "note": "gather time of a rank includes waiting for the slowest rank's encode",
+            }
+        if world == 1 and not args.no_extras and K > 0:
+            # ---- decode of the codes just produced + MSE of encode -> decode (qinco_tasks.py:87-148) ----
+            codes_all = mine.reshape(-1, cfg.M_total)
+            eng.decode(codes_all[:args.batch], check=False)
+            torch.cuda.synchronize(dev)
+            eng.profile_enable(True)
+            eng.profile_read()
+            t1 = time.perf_counter()
+            dec = eng.decode(codes_all, check=False)
+            torch.cuda.synchronize(dev)
+            dt_dec = time.perf_counter() - t1
+            prd = eng.profile_read()
+            eng.profile_enable(False)
+            eng.check_codes()
+            _, d_ms, _, d_ach = mlp_roofline(prd)
+            d_exec = executed_share(1)
+            out["decode"] = {"value": codes_all.shape[0] / dt_dec, "unit": "vectors/s", "vectors": int(codes_all.shape[0]),
+                             "gflop_per_vector": eng.flops_per_vector("decode") / 1e9,
+                             "roofline": {"bound": "mfma", "achieved": d_ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": d_ach / PEAK_FP32_MFMA_TFLOPS,
+                                          "frac_executed": d_ach * d_exec / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": d_ms}}
+            xs = torch.cat(batches[W:W + K])
+            out["mse"] = {"value": sqerr_sum(xs, dec) / xs.shape[0], "vectors": int(xs.shape[0]),
+                          "definition": "sum_i |x_i - decode(encode(x_i))|^2 / N (mse_scale 1; metrics.py:51-58)"}
+            del dec, xs
+
+            def timed_encode(xb_list):
+                for xb in xb_list[:1]:
+                    eng.encode(xb, code_dtype=np.uint8)
+                torch.cuda.synchronize(dev)
+                t2 = time.perf_counter()
+                for xb in xb_list:
+                    eng.encode(xb, code_dtype=np.uint8)
+                torch.cuda.synchronize(dev)
+                return sum(len(xb) for xb in xb_list) / (time.perf_counter() - t2)
+            # ---- the reference's default host batch (qinco_cfg.yaml:38): 1024 vectors per call ----
+            small = [batches[W][i:i + 1024] for i in range(0, min(args.batch, 16384), 1024)]
+            out["batch_1024"] = {"value": timed_encode(small), "unit": "vectors/s", "calls": len(small),
+                                 "note": "same engine, one encode call per 1024 distinct vectors"}
+            # ---- greedy search (beam = 1, BASELINE metric: beam in {1, 8}) ----
+            if cfg.B > 1:
+                eng.set_beam(B=1)
+                out["beam1"] = {"value": timed_encode(batches[W:W + min(K, 2)]), "unit": "vectors/s", "A": eng.A, "B": 1,
+                                "gflop_per_vector": eng.flops_per_vector("encode") / 1e9}
+                eng.set_beam(B=cfg.B)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -96,6 +96,12 @@ QINCO_API int qinco_encode(qinco_handle h, const void* x, int x_dtype, int64_t x
 QINCO_API int qinco_decode(qinco_handle h, const void* codes, int code_dtype, int64_t n, float* out, int flags,
                  void* stream);
 
+/* Out-of-range codes on the device-pointer path: qinco_decode cannot fail synchronously (nothing is synchronised), so a
+ * code outside [0, K_m) raises a sticky flag on the device and is decoded as code 0.  qinco_check waits for `stream`
+ * and returns QINCO_ERR_RANGE if any qinco_decode since the last check / host decode saw such a code (the reference
+ * raises torch's index error at qinco_inference.py:70), then clears the flag.  qinco_decode_host checks by itself. */
+QINCO_API int qinco_check(qinco_handle h, void* stream);
+
 /* Host-pointer convenience forms (stage through device buffers owned by the handle; synchronous). */
 QINCO_API int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int64_t x_row_stride_bytes, int64_t n,
                       void* codes_out, int code_dtype, float* xhat_out, int flags);

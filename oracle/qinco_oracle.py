@@ -86,14 +86,37 @@ def step_forward(w: StepWeights, c: np.ndarray, xhat: np.ndarray, qinco1_mode: b
     return out
 
 
+def step_forward_torch(w: StepWeights, c: np.ndarray, xhat: np.ndarray, qinco1_mode: bool) -> np.ndarray:
+    """step_forward with the same op sequence on torch CPU tensors (ATen matmul / relu / add: multi-threaded,
+    like the reference's own CPU path).  Same restatement, different array library: used by bench.py's
+    cpu_baseline so that the reported CPU figure is not limited by numpy's single-threaded element-wise ops."""
+    import torch
+    t = torch.from_numpy
+    with torch.no_grad():
+        ct = t(np.ascontiguousarray(c))
+        z = ct if w.in_proj is None else ct @ t(w.in_proj).T
+        xh = t(np.ascontiguousarray(np.broadcast_to(xhat, z.shape[:-1] + xhat.shape[-1:])))
+        z = z + (torch.cat([z, xh], dim=-1) @ t(w.cat_w).T + t(w.cat_b))
+        for up, down in zip(w.up, w.down):
+            z = z + torch.relu(z @ t(up).T) @ t(down).T
+        out = z if w.out_proj is None else z @ t(w.out_proj).T
+        if not qinco1_mode:
+            out = out + ct
+    return out.numpy()
+
+
 # --------------------------------------------------------------------------------------------------
 # model
 # --------------------------------------------------------------------------------------------------
 class OracleQINCo:
     """Oracle twin of QINCoInferenceWrapper (qinco_inference.py:257-353) on the CPU fp32 path."""
 
-    def __init__(self, sd: dict, *, M: int, K: int, L: int, A: int, B: int, qinco1_mode: bool, ivf: bool = False):
-        """M = number of steps including the IVF step (cfg._M_ivf)."""
+    def __init__(self, sd: dict, *, M: int, K: int, L: int, A: int, B: int, qinco1_mode: bool, ivf: bool = False,
+                 backend: str = "numpy"):
+        """M = number of steps including the IVF step (cfg._M_ivf).  backend: "numpy" (the pinned checker) or "torch"
+        (the codeword MLP on torch CPU ops, see step_forward_torch)."""
+        assert backend in ("numpy", "torch")
+        self._mlp = step_forward if backend == "numpy" else step_forward_torch
         self.sd = {k: np.ascontiguousarray(np.asarray(v, dtype=F32)) for k, v in sd.items()
                    if not k.endswith(("xtarget_mean", "xtarget_var"))}
         self.M, self.K, self.L, self.A, self.B = M, K, L, A, B
@@ -109,9 +132,10 @@ class OracleQINCo:
                              "using a non-zero A value.")  # utils.py:169-172
 
     @classmethod
-    def from_config(cls, cfg, sd: dict) -> "OracleQINCo":
+    def from_config(cls, cfg, sd: dict, backend: str = "numpy") -> "OracleQINCo":
         """cfg: any object with M_total, K, L, A, B, qinco1_mode, ivf (qinco_amd.config.QincoConfig)."""
-        return cls(sd, M=cfg.M_total, K=cfg.K, L=cfg.L, A=cfg.A, B=cfg.B, qinco1_mode=cfg.qinco1_mode, ivf=cfg.ivf)
+        return cls(sd, M=cfg.M_total, K=cfg.K, L=cfg.L, A=cfg.A, B=cfg.B, qinco1_mode=cfg.qinco1_mode, ivf=cfg.ivf,
+                   backend=backend)
 
     # ---- forward (qinco_inference.py:272-283) ---------------------------------------------------
     def __call__(self, x_in, step: str):
@@ -153,7 +177,7 @@ class OracleQINCo:
         d_sub = approx_pairwise_distance(xtarget.reshape(n * F, D), w.sub_codebook)  # :172
         top = topk_smallest(d_sub, A)  # (n*F, A) :173
         cw = w.codebook[top].reshape(n, F, A, D)  # :175
-        out = step_forward(w, cw, xhat[:, :, None, :], self.qinco1_mode)  # :178-188
+        out = self._mlp(w, cw, xhat[:, :, None, :], self.qinco1_mode)  # :178-188
         cand = out + xhat[:, :, None, :]  # :190-191
         cand_flat = cand.reshape(n, F * A, D)
         dists = approx_compute_batch_distances(x[:, None, :], cand_flat)  # :194-199
@@ -165,6 +189,7 @@ class OracleQINCo:
         xnext = np.take_along_axis(cand_flat, idx[:, :, None], axis=1)  # :213-219
         if trace is not None:
             trace[f"top{m}"] = top.reshape(n, F, A)
+            trace[f"dsub{m}"] = d_sub.reshape(n, F, -1)
             trace[f"dists{m}"] = dists
         return xnext, np.concatenate([hist, real[None]], axis=0)  # :222
 
@@ -176,7 +201,7 @@ class OracleQINCo:
         K = w.codebook.shape[0]
         Mc = codes.shape[0]
         cw = np.broadcast_to(w.codebook[None, None], (n, F, K, D))
-        out = step_forward(w, cw, xhat[:, :, None, :], self.qinco1_mode)
+        out = self._mlp(w, cw, xhat[:, :, None, :], self.qinco1_mode)
         cand = out + xhat[:, :, None, :]
         cand_flat = cand.reshape(n, F * K, D)
         dists = approx_compute_batch_distances(x[:, None, :], cand_flat)
@@ -200,7 +225,7 @@ class OracleQINCo:
         xhat = self.steps[0].codebook[codes_MB[0]].copy()
         for m in range(1, self.M):
             w = self.steps[m]
-            xhat = xhat + step_forward(w, w.codebook[codes_MB[m]], xhat, self.qinco1_mode)  # :72-74
+            xhat = xhat + self._mlp(w, w.codebook[codes_MB[m]], xhat, self.qinco1_mode)  # :72-74
         return xhat
 
 

@@ -129,7 +129,10 @@ ivf_assign_kernel(const f32x4* __restrict__ cstream, const float* __restrict__ c
 // codes0[n] = id part of the merged key (and the matching normalised centroid becomes xhat0 via gather_rows)
 __global__ void ivf_finish_kernel(const unsigned long long* __restrict__ best, long N, int* __restrict__ ids) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) ids[i] = (int)(best[i] & 0xffffffffu);
+  if (i < N) {   // a key nobody lowered (NaN input: no distance compares below +inf) keeps the reference's argmin of NaNs = 0
+    const unsigned long long k = best[i];
+    ids[i] = k == ~0ull ? 0 : (int)(k & 0xffffffffu);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

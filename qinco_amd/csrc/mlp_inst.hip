@@ -1,4 +1,6 @@
 // One instance of the fused-MLP kernel: compiled once per QINCO_SHAPE with -DQD= -DQDE= -DQDH= -DQP= -DQVAR=.
+#include <cstdlib>
+
 #include "mlp_kernel.hpp"
 #include "mlp16_kernel.hpp"
 #include "mlp_launch.hpp"
@@ -14,7 +16,14 @@
 // it is not the ring's landing / overwrite protocol; waiting for one more landed group than the protocol needs does not
 // cure it either, so it is not a lag between vmcnt and LDS visibility).  Root cause not identified; the padding costs
 // nothing.
-static constexpr unsigned kExclusiveLds = (QVAR & 64) ? 36u * 1024u : 0u;  // shared ring: 48 KiB static + 36 = 84 > 80
+static unsigned exclusive_lds() {  // shared ring: 48 KiB static + 36 = 84 > 80.  QINCO_RING_PAD_KIB: experiments only
+  static const unsigned pad = [] {
+    const char* e = getenv("QINCO_RING_PAD_KIB");
+    return (unsigned)((e ? atoi(e) : 36) * 1024);
+  }();
+  return (QVAR & 64) ? pad : 0u;
+}
+#define kExclusiveLds exclusive_lds()
 
 extern "C" __attribute__((visibility("hidden")))
 hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::MlpArgs* a, hipStream_t stream) {

@@ -328,19 +328,31 @@ static int ensure_scratch(qinco_handle_s* h) {
   h->uproj = nullptr;
   h->cap_n = 0;
   const size_t n = (size_t)d.max_batch;
-  const size_t Bm = (size_t)(h->B < d.K ? h->B : d.K);   // widest beam (beam_0 = min(B, K))
-  size_t Ae = (size_t)(h->A > 0 ? h->A : d.K);           // candidates per beam
-  if (d.ivf_K > 0 && h->A > 0 && (size_t)h->B > Ae) Ae = (size_t)h->B;  // first QINCo step of an IVF model
-  if (Ae > (size_t)d.K) Ae = (size_t)d.K;
+  // Widest beam and widest candidate set over the steps, walked exactly like encode_chunk does: beam_0 = min(B, K) (1 for
+  // IVF / single-step models), then F <- min(B or 1, F * Ae).  (B > K: the beam grows past beam_0 after step 1.)
+  size_t Bm = 1, Cm = 1;
+  {
+    size_t F = (d.M == 1 || d.ivf_K > 0) ? 1 : (size_t)(h->B < d.K ? h->B : d.K);
+    Bm = F;
+    for (int m = 1; m < d.M; ++m) {
+      const int nc = n_codes(h, m) < d.K ? n_codes(h, m) : d.K;
+      const size_t Ae = (size_t)(h->A > 0 ? nc : d.K);
+      const size_t C = F * Ae;
+      if (C > Cm) Cm = C;
+      const size_t Fo = (size_t)((m < d.M - 1) ? h->B : 1);
+      F = Fo < C ? Fo : C;
+      if (F > Bm) Bm = F;
+    }
+  }
   int rc = 0;
   if ((rc = dev_alloc(h, &h->xn, n * d.D))) return rc;
   for (int i = 0; i < 2; ++i) {
     if ((rc = dev_alloc(h, &h->xhat[i], n * Bm * d.D))) return rc;
     if ((rc = dev_alloc(h, &h->hist[i], n * Bm * d.M))) return rc;
   }
-  if ((rc = dev_alloc(h, &h->top_ids, n * Bm * (Ae > Bm ? Ae : Bm)))) return rc;
-  if ((rc = dev_alloc(h, &h->cand, n * Bm * Ae * d.D))) return rc;
-  if ((rc = dev_alloc(h, &h->dist, n * Bm * Ae))) return rc;
+  if ((rc = dev_alloc(h, &h->top_ids, n * (Cm > Bm ? Cm : Bm)))) return rc;
+  if ((rc = dev_alloc(h, &h->cand, n * Cm * d.D))) return rc;
+  if ((rc = dev_alloc(h, &h->dist, n * Cm))) return rc;
   if (d.ivf_K > 0 && (rc = dev_alloc(h, &h->ivf_best, n))) return rc;
   if (h->ivf_f16) {
     h->ivf_cand_cap = (int)(16 * n + 4096);
@@ -976,6 +988,8 @@ extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int
   return QINCO_OK;
 }
 
+// The range flag is sticky on the device: import_codes_kernel raises it (and decodes the offending code as 0), the
+// next qinco_check / qinco_decode_host reads and clears it.
 static int check_decode_range(qinco_handle_s* h) {
   int flag = 0;
   HIP_TRY(hipMemcpy(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost));
@@ -984,6 +998,13 @@ static int check_decode_range(qinco_handle_s* h) {
     return fail(QINCO_ERR_RANGE, "qinco_decode: a code is outside [0, K)");
   }
   return 0;
+}
+
+extern "C" int qinco_check(qinco_handle h, void* stream) {
+  if (!h) return fail(QINCO_ERR_INVALID, "qinco_check: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  return check_decode_range(h);
 }
 
 extern "C" int qinco_decode_host(qinco_handle h, const void* codes, int code_dtype, int64_t n, float* out, int flags) {
@@ -997,6 +1018,8 @@ extern "C" int qinco_decode_host(qinco_handle h, const void* codes, int code_dty
   const int64_t cap = n < pass ? n : pass;
   if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, (size_t)cap * crow))) return rc;
   if ((rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, (size_t)cap * orow))) return rc;
+  // this call reports its own codes only: a flag left behind by an unchecked device-pointer decode is dropped
+  HIP_TRY(hipMemset(h->err_flag, 0, sizeof(int)));
   for (int64_t i0 = 0; i0 < n; i0 += pass) {
     const int64_t nb = n - i0 < pass ? n - i0 : pass;
     HIP_TRY(hipMemcpy(h->stage_codes, reinterpret_cast<const char*>(codes) + (size_t)i0 * crow, (size_t)nb * crow,

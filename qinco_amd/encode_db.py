@@ -79,10 +79,29 @@ def encode_shard(model: Callable, db_vecs, start: int, end: int, batch: int = 65
     return np.concatenate(parts)
 
 
+def _comm_device(dist, device=None):
+    """Device the collectives' tensors must live on: RCCL (backend "nccl") moves GPU buffers only, gloo CPU ones."""
+    if device is not None:
+        return device
+    if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        import torch
+        return torch.device("cuda", torch.cuda.current_device())
+    return None
+
+
+def _barrier(dist, device=None):
+    dev = _comm_device(dist, device)
+    if dev is not None and getattr(dev, "type", None) == "cuda":
+        dist.barrier(device_ids=[dev.index if dev.index is not None else 0])
+    else:
+        dist.barrier()
+
+
 def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D: int, batch: int = 65536,
-                    dist=None, gather: bool = False, to_device: Optional[Callable] = None):
+                    dist=None, gather: bool = False, to_device: Optional[Callable] = None, device=None):
     """Reference-compatible database encode.  Returns this rank's codes; with gather=True rank 0 returns the
-    whole (N, M) code matrix collected with one collective (other ranks: their own shard).
+    whole (N, M) code matrix collected with one collective (other ranks: their own shard).  `device`: where the
+    collective's buffers live (default: this rank's current GPU under backend "nccl", the host under "gloo").
 
     Files: `<output>` = np.savez_compressed(n_parts, K, M, D) by rank 0; `<base>.part_<rank>.npz` = codes
     (search_tasks.py:119-134; the reference logs `.{rank}.npz` but writes `.part_{rank}.npz`)."""
@@ -90,13 +109,13 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
     base = output[:-4]
     rank, world = _dist_info(dist)
     if world > 1:
-        dist.barrier()
+        _barrier(dist, device)
     start, end = shard_bounds(len(db_vecs), world, rank)
     codes = encode_shard(model, db_vecs, start, end, batch, to_device)
     if codes.size == 0:
         codes = np.zeros((0, M), np.int64)
     if world > 1:
-        dist.barrier()
+        _barrier(dist, device)
     if rank == 0:
         d = os.path.dirname(output)
         if d:
@@ -104,9 +123,9 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
         np.savez_compressed(output, n_parts=world, K=K, M=M, D=D)
     np.savez_compressed(base + f".part_{rank}.npz", codes=codes)
     if world > 1:
-        dist.barrier()
+        _barrier(dist, device)
     if gather:
-        return gather_codes(codes, len(db_vecs), dist)
+        return gather_codes(codes, len(db_vecs), dist, device=device)
     return codes
 
 
@@ -118,6 +137,7 @@ def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None) -> Op
     if world == 1:
         return codes_local
     import torch
+    device = _comm_device(dist, device)
     M = codes_local.shape[1]
     small = codes_local.size == 0 or int(codes_local.max()) < 256
     flag = torch.tensor([1 if small else 0], dtype=torch.int32, device=device)

@@ -149,9 +149,11 @@ class QincoEngine:
             flags))
         return (codes, xhat) if return_xhat else codes
 
-    def decode(self, codes, normalised: bool = False):
+    def decode(self, codes, normalised: bool = False, check: bool = True):
         """codes: (n, M) int64 / int32 / uint8, numpy or torch CUDA tensor.  Returns (n, D) float32, denormalised
-        (forward(step="decode")) unless normalised=True (QINCoInferenceWrapper.decode)."""
+        (forward(step="decode")) unless normalised=True (QINCoInferenceWrapper.decode).  Codes outside [0, K) raise
+        IndexError like the reference's indexing does; on the device path that costs a stream synchronisation
+        (qinco_check) -- check=False keeps the call asynchronous and leaves the check to a later `check_codes()`."""
         M, D = self.cfg.M_total, self.cfg.D
         flags = _lib.FLAG_NORMALISED if normalised else 0
         if _is_torch(codes) and codes.is_cuda:
@@ -166,6 +168,8 @@ class QincoEngine:
             cdt = {torch.int64: _lib.CODE_I64, torch.int32: _lib.CODE_I32, torch.uint8: _lib.CODE_U8}[codes.dtype]
             st = torch.cuda.current_stream(codes.device).cuda_stream
             _lib.check(self.lib.qinco_decode(self._h, codes.data_ptr(), cdt, n, out.data_ptr(), flags, st))
+            if check:
+                _lib.check(self.lib.qinco_check(self._h, st))
             return out
         if _is_torch(codes):
             codes = codes.detach().cpu().numpy()
@@ -180,6 +184,15 @@ class QincoEngine:
         _lib.check(self.lib.qinco_decode_host(self._h, codes.ctypes.data, _CODE_DT[codes.dtype], n, out.ctypes.data,
                                               flags))
         return out
+
+    def check_codes(self, stream=None):
+        """Wait for `stream` (default: the current torch stream, else the null stream) and raise IndexError if a
+        device-path decode since the last check saw a code outside [0, K) (include/qinco_hip.h: qinco_check)."""
+        if stream is None:
+            import sys
+            torch = sys.modules.get("torch")
+            stream = torch.cuda.current_stream().cuda_stream if torch is not None and torch.cuda.is_available() else None
+        _lib.check(self.lib.qinco_check(self._h, stream))
 
     # ------------------------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):

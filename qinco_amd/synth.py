@@ -24,13 +24,16 @@ def synth_state_dict(cfg: QincoConfig, seed: int = 1234, gain: float = 0.6,
     def lin(o, i):
         return (rs.randn(o, i) * (gain / np.sqrt(i))).astype(F32)
 
+    # codebook scale per step: 0.6^m up to 8 steps; deeper models decay more slowly so that the last step
+    # is as large as an 8-step model's (0.6^8), else fp32 distances of the deep steps tie exactly by the hundreds
+    decay = 0.6 if cfg.M <= 8 else 0.6 ** (8.0 / cfg.M)
     for m in range(cfg.M_total):
         p = f"steps.{m}."
         if m == 0 and cfg.ivf:
             # IVFBook (qinco_base.py:128-196): a frozen coarse codebook, already in normalised space
             sd[p + "ivf_centroids.weight"] = rs.randn(cfg.ivf_K, D).astype(F32)
             continue
-        cb = (rs.randn(cfg.K, D) * (0.6 ** m)).astype(F32)
+        cb = (rs.randn(cfg.K, D) * (decay ** m)).astype(F32)
         sd[p + "codebook.weight"] = cb
         sd[p + "xtarget_mean"] = np.zeros(D, F32)   # training buffers, unused at inference
         sd[p + "xtarget_var"] = np.ones(D, F32)

@@ -78,7 +78,10 @@ CASES = {
     "C1_qinco1_8x8": (preset("qinco1", D=128, M=8), 1235, 128),
     "C2_qinco2L_8x8_b8": (preset("qinco2-L", D=128, M=8, B=8), 1236, 64),
     "C2_qinco2L_8x8_b1": (preset("qinco2-L", D=128, M=8, B=1), 1236, 64),
-    "C4_qinco2L_d768_b8": (preset("qinco2-L", D=768, M=4, B=8), 1238, 32),
+    "C4_qinco2L_d768_b8": (preset("qinco2-L", D=768, M=8, B=8), 1238, 32),     # BASELINE configs[3] at its real depth
+    "C3_qinco2L_16x8_b8": (preset("qinco2-L", D=128, M=16, B=8), 1237, 64),    # BASELINE configs[2]: M = 16 steps
+    "C2_qinco2L_8x8_b32": (preset("qinco2-L", D=128, M=8, B=32), 1236, 32),    # the presets' own search width (qinco2-L.yaml:13)
+    "tiny_smallK_wideB": (QincoConfig(D=32, M=4, K=64, L=2, de=64, dh=96, A=8, B=128), 17, 64),   # B > K: beam grows past beam_0
     "qinco1_d768": (preset("qinco1", D=768, M=3), 1241, 32),   # De = D = 768: the 16-row tile kernel's shape
     # IVF-QINCo: coarse step of ivf_K centroids, beam_0 = 1, first QINCo step takes max(A, B)
     "tiny_ivf_beam": (QincoConfig(D=32, M=3, K=256, L=2, de=64, dh=96, A=4, B=8, ivf_K=2048), 15, 256),
@@ -104,7 +107,11 @@ def run_case(name: str, cfg: QincoConfig, seed: int, n: int) -> dict:
     wrapper_ok = wrapper is not None
     with torch.no_grad():
         xt = torch.from_numpy(x)
-        codes_base = model(xt, step="encode").numpy()  # (M, N)
+        try:
+            codes_base = model(xt, step="encode").numpy()  # (M, N)
+        except RuntimeError as e:   # the base model's step 0 asks topk for B > K entries; the inference wrapper clamps beam_0
+            assert cfg.B > cfg.K and wrapper_ok, e
+            codes_base = None
         if wrapper_ok:
             codes_w = wrapper(xt, step="encode").numpy()
             _, xhat_norm = wrapper.encode((xt - wrapper.data_mean) / wrapper.data_std)
@@ -113,7 +120,8 @@ def run_case(name: str, cfg: QincoConfig, seed: int, n: int) -> dict:
             dec = wrapper(torch.from_numpy(codes_w), step="decode").numpy()
         else:
             dec = model(torch.from_numpy(codes_base), step="decode").numpy()
-        out["codes_base"] = codes_base.T.copy()
+        if codes_base is not None:
+            out["codes_base"] = codes_base.T.copy()
         out["decoded"] = dec
         # decode of arbitrary codes (not produced by encode)
         rc2 = synth_codes(cfg, 96, seed=seed + 5)
@@ -126,13 +134,20 @@ def run_case(name: str, cfg: QincoConfig, seed: int, n: int) -> dict:
     trace: dict = {}
     xn = (x - oracle.data_mean) / oracle.data_std
     codes_o, xhat_o = oracle.encode(xn, trace)
-    codes_ref = out.get("codes_wrapper", out["codes_base"])
+    codes_ref = out["codes_wrapper"] if "codes_wrapper" in out else out["codes_base"]
     agree = float((codes_o.T == codes_ref).all(axis=1).mean())
     margins = []
     for m in range(1, cfg.M_total):
         d = np.sort(trace[f"dists{m}"], axis=-1)
         fo = min(cfg.B if m < cfg.M_total - 1 else 1, d.shape[1] - 1)
-        margins.append((d[:, fo] - d[:, fo - 1]) / np.maximum(np.abs(d[:, fo]), 1e-12))
+        mg = (d[:, fo] - d[:, fo - 1]) / np.maximum(np.abs(d[:, fo]), 1e-12)
+        if f"dsub{m}" in trace:   # pre-selection boundary: A-th vs (A+1)-th codeword of each beam's table
+            ds = np.sort(trace[f"dsub{m}"], axis=-1)
+            a = trace[f"top{m}"].shape[-1]
+            if a < ds.shape[-1]:
+                pm = ((ds[..., a] - ds[..., a - 1]) / np.maximum(np.abs(ds[..., a]), 1e-12)).min(axis=1)
+                mg = np.minimum(mg, pm)
+        margins.append(mg)
         if f"top{m}" in trace:
             out[f"oracle_top{m}"] = trace[f"top{m}"].astype(np.int16)
     if cfg.ivf:  # margin of the coarse assignment (step 0)
@@ -142,7 +157,7 @@ def run_case(name: str, cfg: QincoConfig, seed: int, n: int) -> dict:
     mse_ref = float(((x - dec) ** 2).sum(-1).mean())
     out["mse"] = np.float64(mse_ref)
     print(f"{name:24s} N={len(x):4d} wrapper==base: "
-          f"{bool((out['codes_base'] == codes_ref).all())}  oracle==ref rows: {agree:.4f}  "
+          f"{bool((out.get('codes_base', codes_ref) == codes_ref).all())}  oracle==ref rows: {agree:.4f}  "
           f"min margin {out['select_rel_margin'].min():.2e}  mse {mse_ref:.4f}")
     return out
 

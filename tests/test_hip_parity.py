@@ -8,7 +8,7 @@ row must have a recorded relative margin below NEAR_TIE, and the test prints the
 import numpy as np
 import pytest
 
-from conftest import golden_cases, load_golden, make_oracle, ref_codes
+from conftest import ROOT, assert_only_near_ties, golden_cases, load_golden, make_oracle, ref_codes
 
 pytestmark = pytest.mark.gpu
 
@@ -53,17 +53,21 @@ def test_encode_matches_reference_golden(engines, name):
             m = float(g["ivf_rel_margin"][i])
         assert first > 0 or "ivf_rel_margin" in g, "step-0 codes can only differ on an exact tie"
         assert m < NEAR_TIE, f"row {i}: codes differ although the reference margin is {m:.3e}"
-    if cfg.B == 1:
-        assert len(bad) == 0, f"greedy codes must be bit-identical to the reference ({len(bad)} rows differ)"
-    assert len(bad) <= max(1, len(want) // 50)
+    # (no cap on the count: every differing row has just been shown to sit on a rounding-level tie of the reference)
     ok = np.setdiff1d(np.arange(len(want)), bad)
     if "xhat_norm_wrapper" in g:
         assert rel_err(xhat[ok], g["xhat_norm_wrapper"][ok]) < REL_TOL
-    # MSE of the full pipeline (encode -> decode) vs the reference's
+    # the full pipeline (encode -> decode) vs the reference's: row by row where the codes agree, so the MSE over those
+    # rows is within REL_TOL; a row that took the other side of a tie must still be as good a reconstruction
     dec = eng.decode(codes)
-    mse = float(((g["x"] - dec) ** 2).sum(-1).mean())
-    assert abs(mse - float(g["mse"])) / float(g["mse"]) < REL_TOL * max(1, 200 * len(bad))
     assert rel_err(dec[ok], g["decoded"][ok]) < REL_TOL
+    err_g = ((g["x"] - dec) ** 2).sum(-1)
+    err_r = ((g["x"] - g["decoded"]) ** 2).sum(-1)
+    assert abs(err_g[ok].mean() - err_r[ok].mean()) / err_r[ok].mean() < REL_TOL
+    if len(bad) == 0:
+        assert abs(float(err_g.mean()) - float(g["mse"])) / float(g["mse"]) < REL_TOL
+    else:
+        assert abs(err_g[bad].mean() - err_r[bad].mean()) / err_r[bad].mean() < 2e-2
 
 
 @pytest.mark.parametrize("name", list(golden_cases().keys()))
@@ -89,16 +93,15 @@ def test_encode_matches_oracle_fresh_inputs(engines, name, n):
     oracle = make_oracle(cfg, sd)
     want = oracle(x, step="encode").T
     got = eng.encode(x)
-    bad = np.nonzero((got != want).any(axis=1))[0]
-    print(f"{name}: {len(bad)}/{n} rows differ from the oracle")
-    assert len(bad) <= max(1, n // 50)
-    if cfg.B == 1:
-        assert len(bad) <= 1
+    nbad = assert_only_near_ties(oracle, x, got, want, NEAR_TIE, name)   # greedy or beam: ties only
+    print(f"{name}: {nbad}/{n} rows differ from the oracle (all on rounding-level ties)")
+    ok = (got == want).all(axis=1)
     x_o = oracle(want.T, step="decode")
     x_g = eng.decode(got)
-    mse_o = float(((x - x_o) ** 2).sum(-1).mean())
-    mse_g = float(((x - x_g) ** 2).sum(-1).mean())
-    assert abs(mse_o - mse_g) / mse_o < REL_TOL * max(1, 200 * len(bad))
+    assert rel_err(x_g[ok], x_o[ok]) < REL_TOL
+    mse_o = float(((x[ok] - x_o[ok]) ** 2).sum(-1).mean())
+    mse_g = float(((x[ok] - x_g[ok]) ** 2).sum(-1).mean())
+    assert abs(mse_o - mse_g) / mse_o < REL_TOL
 
 
 def test_ragged_and_chunked_batches(engines):
@@ -165,7 +168,7 @@ def test_set_beam_changes_search_width(engines):
     eng.set_beam(A=8, B=1)
     m1 = mse(eng.encode(x))
     o = make_oracle(cfg.with_search(B=1), sd)
-    assert (eng.encode(x) != o(x, step="encode").T).any(axis=1).sum() <= 4
+    assert_only_near_ties(o, x, eng.encode(x), o(x, step="encode").T, NEAR_TIE, "set_beam B=1")
     eng.set_beam(A=16, B=8)
     m8 = mse(eng.encode(x))
     eng.set_beam(A=cfg.A, B=cfg.B)
@@ -279,8 +282,7 @@ def test_every_kernel_instance_matches_oracle(shape):
     got = eng.encode(x)
     oracle = make_oracle(cfg, sd)
     want = oracle(x, step="encode").T
-    bad = int((got != want).any(axis=1).sum())
-    assert bad <= 2, f"{bad} of {len(x)} rows differ"
+    assert_only_near_ties(oracle, x, got, want, NEAR_TIE, "x".join(map(str, shape)))
     dec = eng.decode(want)
     ref = oracle(want.T, step="decode")
     assert np.abs(dec - ref).max() / np.abs(ref).max() < REL_TOL
@@ -294,8 +296,9 @@ def test_model_without_ffn_blocks_uses_fallback_instance():
     sd = synth_state_dict(cfg, 5)
     x = synth_vectors(cfg, sd, 100, seed=3)
     eng = QincoEngine(cfg, sd, max_batch=64)
-    want = make_oracle(cfg, sd)(x, step="encode").T
-    assert (eng.encode(x) != want).any(axis=1).sum() <= 1
+    oracle = make_oracle(cfg, sd)
+    want = oracle(x, step="encode").T
+    assert_only_near_ties(oracle, x, eng.encode(x), want, NEAR_TIE, "L=0")
     eng.close()
 
 
@@ -318,7 +321,7 @@ def test_small_models_at_large_batches_are_exact_and_deterministic(variant, monk
         runs = [eng.encode(x, return_xhat=True) for _ in range(3)]
         for codes, xhat in runs:
             assert np.array_equal(codes, runs[0][0]) and np.array_equal(xhat, runs[0][1])
-        assert (runs[0][0] != want).any(axis=1).sum() <= 3000 // 500
+        assert_only_near_ties(oracle, x, runs[0][0], want, NEAR_TIE, f"small model {kw}")
         ref = (oracle(runs[0][0].T, step="decode") - oracle.data_mean) / oracle.data_std
         assert np.abs(runs[0][1] - ref).max() / np.abs(ref).max() < REL_TOL
         eng.close()
@@ -397,3 +400,140 @@ def test_model_exposes_inner_model_attribute_path():
     assert tuple(w.shape) == (cfg.ivf_K, cfg.D) and np.array_equal(np.asarray(w), sd["steps.0.ivf_centroids.weight"])
     assert np.array_equal(np.asarray(model.qinco_model.steps[1].codebook.weight), sd["steps.1.codebook.weight"])
     assert len(model.get_codebooks_refs()) == cfg.M
+
+
+def test_bench_shape_batch_matches_oracle_on_scattered_rows():
+    """bench.py's configuration itself (C2, 16 384 vectors in ONE pass at max_batch = 16 384: 2 M MLP rows per launch):
+    64 rows scattered over the batch against the oracle."""
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    from qinco_amd.config import BASELINE_CONFIGS
+    cfg = BASELINE_CONFIGS["C2"]
+    sd = synth_state_dict(cfg, 1236)
+    n = 16384
+    x = synth_vectors(cfg, sd, n, seed=31337)
+    eng = QincoEngine(cfg, sd, max_batch=n)
+    codes, xhat_n = eng.encode(x, return_xhat=True)
+    rows = np.unique(np.concatenate([[0, 1, 127, 128, n // 2 - 1, n // 2, n - 2, n - 1],
+                                     np.random.RandomState(5).randint(0, n, 56)]))
+    oracle = make_oracle(cfg, sd)
+    want = oracle(x[rows], step="encode").T
+    nbad = assert_only_near_ties(oracle, x[rows], codes[rows], want, NEAR_TIE, "C2 @ 16384")
+    ok = (codes[rows] == want).all(axis=1)
+    ref = (oracle(want.T, step="decode") - oracle.data_mean) / oracle.data_std
+    assert rel_err(xhat_n[rows][ok], ref[ok]) < REL_TOL
+    print(f"C2 batch 16384: {nbad} of {len(rows)} sampled rows on a tie")
+    eng.close()
+
+
+def test_from_checkpoint_runs_encode_database_on_the_gpu(tmp_path):
+    """a11 + a12 through the product path: a checkpoint written by the reference's save_model -> QINCoHIP.from_checkpoint
+    -> encode_database (part files, header) -> EncodedDBIterator -> decode, against the oracle."""
+    from conftest import GOLDEN
+    from qinco_amd.checkpoint import load_checkpoint
+    from qinco_amd.encode_db import EncodedDBIterator, encode_database
+    from qinco_amd.model import QINCoHIP
+    from qinco_amd import synth_vectors
+    model = QINCoHIP.from_checkpoint(str(GOLDEN / "tiny_ckpt.pt"), max_batch=128)
+    cfg, sd = load_checkpoint(str(GOLDEN / "tiny_ckpt.pt"))
+    assert model.built and model.cfg == cfg
+    db = synth_vectors(cfg, sd, 517, seed=8)
+    out = str(tmp_path / "enc" / "db.npz")
+    codes = encode_database(model, db, out, K=cfg.K, M=cfg.M, D=cfg.D, batch=200)
+    oracle = make_oracle(cfg, sd)
+    want = oracle(db, step="encode").T
+    assert codes.dtype == np.int64 and codes.shape == want.shape
+    assert_only_near_ties(oracle, db, codes, want, NEAR_TIE, "from_checkpoint")
+    it = EncodedDBIterator(out, K=cfg.K, M=cfg.M, D=cfg.D)
+    assert it.n_parts == 1 and np.array_equal(it.load_all(), codes)
+    dec = model(codes.T, step="decode")
+    assert rel_err(dec, oracle(codes.T, step="decode")) < REL_TOL
+    # the CLI-style override of the stored search width (utils.py:166-172)
+    greedy = QINCoHIP.from_checkpoint(str(GOLDEN / "tiny_ckpt.pt"), B=1, max_batch=128)
+    og = make_oracle(cfg.with_search(B=1), sd)
+    assert_only_near_ties(og, db[:200], greedy(db[:200], step="encode").T, og(db[:200], step="encode").T, NEAR_TIE, "B=1")
+
+
+def test_device_path_decode_reports_out_of_range_codes(engines):
+    """qinco_decode (device pointers, asynchronous) cannot fail by itself: the engine checks the device flag after the
+    call (qinco_check) and raises the reference's IndexError; an unchecked call must not poison a later host decode."""
+    import torch
+    cfg, sd, eng = engines("tiny_id_qinco1")
+    good = np.zeros((5, cfg.M), np.int64)
+    bad = good.copy()
+    bad[3, 2] = cfg.K
+    with pytest.raises(IndexError):
+        eng.decode(torch.from_numpy(bad).cuda())
+    assert np.array_equal(eng.decode(torch.from_numpy(good).cuda()).cpu().numpy(), eng.decode(good))
+    eng.decode(torch.from_numpy(bad).cuda(), check=False)      # asynchronous form: flag stays on the device ...
+    with pytest.raises(IndexError):
+        eng.check_codes()                                       # ... until somebody asks
+    eng.check_codes()                                           # and is cleared by the check
+    eng.decode(torch.from_numpy(bad).cuda(), check=False)
+    eng.decode(good)                                            # a host decode reports its own codes only
+    with pytest.raises(IndexError):
+        eng.decode(bad)
+    neg = good.copy()
+    neg[0, 0] = -1
+    with pytest.raises(IndexError):
+        eng.decode(torch.from_numpy(neg).cuda())
+
+
+def test_nan_input_on_the_ivf_path_stays_in_range():
+    """A NaN vector has no nearest centroid (every comparison is false): the coarse code must stay a valid index (argmin of
+    NaNs = 0 in the reference) instead of -1 / an out-of-bounds gather."""
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    cfg, seed = golden_cases()["tiny_ivf_beam"]
+    sd = synth_state_dict(cfg, seed)
+    eng = QincoEngine(cfg, sd, max_batch=256)
+    x = synth_vectors(cfg, sd, 40, seed=2)
+    clean = eng.encode(x)
+    x[7, :] = np.nan
+    codes = eng.encode(x)
+    assert codes.min() >= 0 and codes[:, 0].max() < cfg.ivf_K and (codes[:, 1:] < cfg.K).all()
+    keep = np.arange(40) != 7
+    assert np.array_equal(codes[keep], clean[keep])
+    eng.close()
+
+
+def _stress_worker(wl, n, out):
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    from qinco_amd.config import BASELINE_CONFIGS
+    cfg = BASELINE_CONFIGS[wl]
+    sd = synth_state_dict(cfg, 1236)
+    x = synth_vectors(cfg, sd, n, seed=123)
+    eng = QincoEngine(cfg, sd, max_batch=8192)
+    c1, h1 = eng.encode(x, return_xhat=True)
+    c2, h2 = eng.encode(x, return_xhat=True)
+    assert np.array_equal(c1, c2) and np.array_equal(h1, h2), "run-to-run nondeterminism"
+    np.savez(out, codes=c1, xhat=h1)
+
+
+@pytest.mark.parametrize("wl", ["C1", "C2"])
+def test_weight_delivery_variants_agree_bitwise(wl, tmp_path):
+    """Race detector for the hand-counted vmcnt / barrier protocol of the weight rings: the register ring of plain loads,
+    the per-wave LDS-DMA rings and the workgroup-shared ring differ only in HOW fragments reach the MFMA, so codes AND
+    reconstructions of a large batch must agree bit for bit (and run to run); the folded production kernel (different
+    fp32 association) may differ from them on near-ties only."""
+    import os
+    import subprocess
+    import sys
+    n = 16384
+    res = {}
+    for var in ["", "48,92", "48,76", "36,12", "8,0"]:
+        env = dict(os.environ)
+        env.pop("QINCO_MLP_VARIANT", None)
+        if var:
+            env["QINCO_MLP_VARIANT"] = var
+        out = str(tmp_path / f"v_{var.replace(',', '_')}.npz")
+        code = (f"import sys; sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(ROOT / 'tests')!r}); "
+                f"from test_hip_parity import _stress_worker; _stress_worker({wl!r}, {n}, {out!r})")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+        res[var or "production"] = dict(np.load(out))
+    base = res["48,76"]
+    for k in ("36,12", "8,0"):
+        assert np.array_equal(res[k]["codes"], base["codes"]) and np.array_equal(res[k]["xhat"], base["xhat"]), k
+    for k in ("production", "48,92"):
+        diff = int((res[k]["codes"] != base["codes"]).any(axis=1).sum())
+        print(f"{wl}: {k} (folded head) vs unfolded: {diff} of {n} code rows differ")
+        assert diff <= n // 1000

@@ -1,0 +1,113 @@
+"""N > 1 on the GPU box: the HIP engine behind encode_database with one process per rank (reference
+search_tasks.py:85-137 + run.sh:8), and bench.py's own multi-rank launch.  Codes from P ranks must equal the 1-process
+HIP codes bitwise."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(world, outdir, backend, n, dev_input=False):
+    port = str(_free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "rank_worker.py"), str(r), str(world), port, str(outdir),
+                               backend, str(n)] + (["dev"] if dev_input else []), env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+
+
+def _single_process_codes(n):
+    from qinco_amd import synth_state_dict, synth_vectors
+    from qinco_amd.model import QINCoHIP
+    cfg, seed = golden_cases()["tiny_proj_beam"]
+    sd = synth_state_dict(cfg, seed)
+    model = QINCoHIP(cfg, sd, max_batch=256)
+    want = model(synth_vectors(cfg, sd, n, seed=4), step="encode").T
+    model.engine.close()
+    return cfg, np.asarray(want)
+
+
+def _check_outputs(tmp_path, world, n):
+    from qinco_amd.encode_db import EncodedDBIterator, shard_bounds
+    cfg, want = _single_process_codes(n)
+    got = np.load(tmp_path / "gathered.npy")
+    assert got.dtype == np.int64 and np.array_equal(got, want)
+    it = EncodedDBIterator(str(tmp_path / "db.npz"), K=cfg.K, M=cfg.M, D=cfg.D)
+    assert it.n_parts == world and np.array_equal(it.load_all(), want)
+    for r in range(world):
+        s, e = shard_bounds(n, world, r)
+        part = np.load(tmp_path / f"db.part_{r}.npz")["codes"]
+        assert part.dtype == np.int64 and np.array_equal(part, want[s:e])
+
+
+@pytest.mark.parametrize("world,n,dev_input", [(2, 1203, False), (3, 700, True)])
+def test_ranks_sharing_one_gpu_gloo(tmp_path, world, n, dev_input):
+    """Each rank owns a QincoEngine on GPU 0 (the 1-GPU box); collectives on gloo."""
+    _run_ranks(world, tmp_path, "gloo", n, dev_input)
+    _check_outputs(tmp_path, world, n)
+
+
+def test_two_ranks_rccl(tmp_path):
+    """One GPU per rank, backend nccl (= RCCL): barriers and the gather of the codes run on device buffers."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    _run_ranks(2, tmp_path, "nccl", 1203, True)
+    _check_outputs(tmp_path, 2, 1203)
+
+
+def _bench(*args):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_ranks_from_a_bare_python():
+    """`python bench.py --gpus 2` without torchrun: the script re-executes itself under torch.distributed.run."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    rec = _bench("--gpus", "2", "--backend", backend, "--workload", "C1", "--batch", "512", "--steps", "2", "--warmup", "1")
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    mg = rec["multi_gpu"]
+    assert len(mg["per_rank_encode_vectors_per_s"]) == 2 and all(v > 0 for v in mg["per_rank_encode_vectors_per_s"])
+    assert len(mg["per_rank_gather_s"]) == 2 and mg["gather_bytes_per_rank"] == 2 * 512 * 8
+    assert abs(rec["value"] - 2 * 2 * 512 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 1e-6
+
+
+def test_bench_line_schema_single_gpu():
+    """A short single-GPU run carries every field of the contract line plus roofline / decode / mse / batch_1024."""
+    rec = _bench("--workload", "C1", "--batch", "2048", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "decode", "mse", "batch_1024"):
+        assert k in rec, k
+    rf = rec["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac_executed"] <= 1.0 and rf["frac_executed"] <= rf["frac"] + 1e-9
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rec["decode"]["value"] > rec["value"] and 0 < rec["decode"]["roofline"]["frac_executed"] <= 1.0
+    assert rec["mse"]["value"] > 0 and rec["mse"]["vectors"] == 2 * 2048
+    assert rec["config"]["distinct_vectors_encoded"] == 2 * 2048

@@ -164,6 +164,11 @@ QINCO_API int qinco_knn_search_host(qinco_knn knn, const float* db, int64_t n, c
  * accumulated in fp64); synchronises `stream`. */
 QINCO_API int qinco_sqerr_sum(const float* a, const float* b, int64_t count, double* sum_out, void* stream);
 
+/* Device self-test of the in-wave sort / top-T selection primitives the table and beam kernels are built on, against a host
+ * computation (random data, heavy ties, NaN / inf).  QINCO_OK, or QINCO_ERR_HIP with the first discrepancy in
+ * qinco_last_error().  Runs on the current device; synchronous. */
+QINCO_API int qinco_selftest(void);
+
 QINCO_API const char* qinco_last_error(void);
 QINCO_API const char* qinco_version(void);
 

@@ -18,7 +18,7 @@ API_SYMBOLS = [
     "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
     "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
-    "qinco_ivf_last_stats", "qinco_check", "qinco_knn_create", "qinco_knn_destroy", "qinco_knn_search", "qinco_knn_search_host", "qinco_sqerr_sum",
+    "qinco_ivf_last_stats", "qinco_check", "qinco_selftest", "qinco_knn_create", "qinco_knn_destroy", "qinco_knn_search", "qinco_knn_search_host", "qinco_sqerr_sum",
 ]
 
 
@@ -92,6 +92,8 @@ def load() -> C.CDLL:
     lib.qinco_encode_host.argtypes = [vp, vp, i32, i64, i64, vp, i32, vp, i32]
     lib.qinco_decode_host.argtypes = [vp, vp, i32, i64, vp, i32]
     lib.qinco_check.argtypes = [vp, vp]
+    lib.qinco_selftest.argtypes = []
+    lib.qinco_selftest.restype = C.c_int
     lib.qinco_check.restype = C.c_int
     lib.qinco_profile_enable.argtypes = [vp, i32]
     lib.qinco_profile_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl)]

@@ -74,6 +74,139 @@ QINCO_DEV void wave_argmin(float& v, int& i) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Top-T selection of a wave: threshold-and-compact instead of T dependent arg-min rounds.
+//   1. every lane reduces its elements (index = lane, lane + 64, ...) to a lane minimum;
+//   2. one bitonic sort of the 64 lane minima across the wave (21 compare-exchange steps on DPP row permutes and
+//      gfx950's v_permlane16/32_swap, 3-5 VALU ops each); the value tau now in lane T-1 bounds the T-th smallest
+//      element from above, because T lanes hold an element <= tau;
+//   3. the elements <= tau (T <= S; S ~ 1.1 T .. 1.4 T for 2-8 elements per lane) are compacted into LDS as 64-bit
+//      (ordered distance bits, index) keys with ballot / mbcnt;
+//   4. every survivor counts the survivors with a smaller key: its rank in the exact lexicographic (distance, index)
+//      order = its output slot (ascending, ties -> lower index: argmin / stable argsort, qinco_inference.py:173,200).
+// ~170 VALU ops per selection against T x ~40 dependent ones.  Needs T <= 64 and S <= 64 (else the caller falls back to the
+// rounds: massive exact ties only).  NaN distances sort last.  All 64 lanes must be active.
+// ---------------------------------------------------------------------------------------------
+QINCO_DEV unsigned sel_key(float d) { return d != d ? 0xffffffffu : ordered_bits(d); }
+
+QINCO_DEV unsigned sel_pick(unsigned lo, unsigned hi, unsigned long long keepmin) {
+  unsigned r;   // r = keepmin[lane] ? lo : hi, the lane mask being a compile-time constant in an SGPR pair
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(keepmin));
+  return r;
+}
+template <int K, int J>
+constexpr unsigned long long sel_keepmin_mask() {
+  unsigned long long m = 0;
+  for (int i = 0; i < 64; ++i) {
+    const bool up = K >= 64 || (i & K) == 0;   // ascending block
+    const bool low = (i & J) == 0;             // lower lane of its pair
+    if (up == low) m |= 1ull << i;
+  }
+  return m;
+}
+QINCO_DEV unsigned sel_umax(unsigned a, unsigned b) { return a > b ? a : b; }
+// compare-exchange with the lane J away inside a bitonic block of size K
+template <int K, int J>
+QINCO_DEV unsigned sel_cmpx(unsigned x) {
+  unsigned lo, hi;
+  if constexpr (J == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);   // {even-row copy, odd-row copy} of each row pair
+    lo = umin((unsigned)r[0], (unsigned)r[1]);
+    hi = sel_umax((unsigned)r[0], (unsigned)r[1]);
+  } else if constexpr (J == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    lo = umin((unsigned)r[0], (unsigned)r[1]);
+    hi = sel_umax((unsigned)r[0], (unsigned)r[1]);
+  } else {
+    unsigned p;
+    if constexpr (J == 1) p = dpp_u<0xB1>(x);         // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) p = dpp_u<0x4E>(x);    // quad_perm [2,3,0,1]
+    else if constexpr (J == 8) p = dpp_u<0x128>(x);   // row_ror:8
+    else {                                            // J == 4: banks 0,2 read lane+4 (row_shl:4), banks 1,3 lane-4
+      static_assert(J == 4, "");
+      p = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xF, 0x5, false);
+      p = (unsigned)__builtin_amdgcn_update_dpp((int)p, (int)x, 0x114, 0xF, 0xA, false);
+    }
+    lo = umin(x, p);
+    hi = sel_umax(x, p);
+  }
+  return sel_pick(lo, hi, sel_keepmin_mask<K, J>());
+}
+template <int K, int J>
+QINCO_DEV unsigned sel_merge(unsigned x) {
+  x = sel_cmpx<K, J>(x);
+  if constexpr (J > 1) x = sel_merge<K, J / 2>(x);
+  return x;
+}
+// ascending across the 64 lanes
+QINCO_DEV unsigned wave_sort64(unsigned x) {
+  x = sel_merge<2, 1>(x);
+  x = sel_merge<4, 2>(x);
+  x = sel_merge<8, 4>(x);
+  x = sel_merge<16, 8>(x);
+  x = sel_merge<32, 16>(x);
+  x = sel_merge<64, 32>(x);
+  return x;
+}
+
+constexpr int SEL_SURV = 72;   // LDS entries (64-bit) a wave needs for wave_select_smallest: 64 survivors + padding to 8
+
+// dv[0..C) distances in LDS (wave-private).  On success every survivor lane p < S holds one selected candidate:
+// rank < T -> (rank, index) is an output pair; other lanes get rank = -1.  Returns false if the caller must fall back.
+QINCO_DEV bool wave_select_smallest(const float* dv, int C, int T, unsigned long long* surv, int lane, int& rank, int& index) {
+  rank = -1;
+  index = 0;
+  if (T > 64) return false;
+  unsigned lm = 0xffffffffu;
+  for (int k = lane; k < C; k += 64) lm = umin(lm, sel_key(dv[k]));
+  const unsigned sorted = wave_sort64(lm);
+  const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)sorted, T - 1);
+  int S = 0;
+  for (int k0 = 0; k0 < C; k0 += 64) {
+    const int k = k0 + lane;
+    const unsigned key = k < C ? sel_key(dv[k]) : 0xffffffffu;
+    const bool m = k < C && key <= tau;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(m);
+    const int pos = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    if (m && pos < 64) surv[pos] = ((unsigned long long)key << 32) | (unsigned)k;
+    S += __builtin_popcountll(mask);
+  }
+  if (S > 64) return false;
+  if (lane < 8) surv[S + lane] = ~0ull;   // pad to a multiple of 8 for the unrolled count
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long mine = lane < S ? surv[lane] : ~0ull;
+  int r = 0;
+  for (int j0 = 0; j0 < S; j0 += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r += surv[j0 + u] < mine ? 1 : 0;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < S && r < T) {
+    rank = r;
+    index = (int)(unsigned)mine;
+  }
+  return true;
+}
+
+// self-test kernels (qinco_selftest): one wave per problem
+__global__ void __launch_bounds__(64) selftest_sort_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out) {
+  const int lane = threadIdx.x;
+  out[(long)blockIdx.x * 64 + lane] = wave_sort64(in[(long)blockIdx.x * 64 + lane]);
+}
+__global__ void __launch_bounds__(64) selftest_select_kernel(const float* __restrict__ d, int C, int T, int* __restrict__ ids,
+                                                             int* __restrict__ fell_back) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  float* dv = lds;
+  unsigned long long* surv = reinterpret_cast<unsigned long long*>(lds + ((C + 3) & ~3));
+  for (int k = lane; k < C; k += 64) dv[k] = d[(long)blockIdx.x * C + k];
+  __builtin_amdgcn_wave_barrier();
+  int rank, index;
+  const bool ok = wave_select_smallest(dv, C, T, surv, lane, rank, index);
+  if (ok && rank >= 0) ids[(long)blockIdx.x * T + rank] = index;
+  if (lane == 0) fell_back[blockIdx.x] = ok ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------------------------
 // K8: x_n = (x - mean) / std   (qinco_inference.py:277).  x is fp32 or uint8 rows with a byte stride
 // (bvecs rows are d+4 bytes apart: search_tasks.py:109-110 converts the raw slice with .to(float32)).
 // ---------------------------------------------------------------------------------------------
@@ -241,33 +374,50 @@ beam_select_kernel(const float* __restrict__ dist, const float* __restrict__ can
   const long n = (long)blockIdx.x * 4 + wave;
   if (n >= N) return;   // wave-uniform; only wave-level sync below
   const int C = F * A;
-  float* dv = lds + (long)wave * C;
+  // per wave: C distances, the T selected flat indices, the survivor list of wave_select_smallest
+  const int per_wave = ((C + T + 3) & ~3) + 2 * SEL_SURV;
+  float* dv = lds + (long)wave * per_wave;
+  int* sel = reinterpret_cast<int*>(dv + C);
+  unsigned long long* surv = reinterpret_cast<unsigned long long*>(dv + ((C + T + 3) & ~3));
   const float* dsrc = dist + n * C;
   for (int k = lane; k < C; k += 64) dv[k] = dsrc[k];
   __builtin_amdgcn_wave_barrier();
-  for (int t = 0; t < T; ++t) {
-    float bv = __builtin_inff();
-    int bi = 0x7fffffff;
-    for (int k = lane; k < C; k += 64) {  // k ascends: strict < keeps the lowest index
-      const float v = dv[k];
-      const bool take = v < bv;
-      bv = take ? v : bv;
-      bi = take ? k : bi;
+  int rank, index;
+  if (T > 1 && wave_select_smallest(dv, C, T, surv, lane, rank, index)) {
+    if (rank >= 0) sel[rank] = index;
+  } else {   // T == 1 (one arg-min round is already minimal), or massive ties: T rounds of arg-min
+    for (int t = 0; t < T; ++t) {
+      float bv = __builtin_inff();
+      int bi = 0x7fffffff;
+      for (int k = lane; k < C; k += 64) {  // k ascends: strict < keeps the lowest index
+        const float v = dv[k];
+        const bool take = v < bv;
+        bv = take ? v : bv;
+        bi = take ? k : bi;
+      }
+      wave_argmin(bv, bi);
+      if (bi == 0x7fffffff) bi = 0;           // only NaN / +inf left: degenerate, keep in range
+      if ((bi & 63) == lane) dv[bi] = __builtin_inff();
+      if (lane == 0) sel[t] = bi;
+      __builtin_amdgcn_wave_barrier();
     }
-    wave_argmin(bv, bi);
-    if (bi == 0x7fffffff) bi = 0;
-    if ((bi & 63) == lane) dv[bi] = __builtin_inff();
-    __builtin_amdgcn_wave_barrier();
+  }
+  __builtin_amdgcn_wave_barrier();
+  // parents, codes, history re-threading and the xhat gather of all T survivors, spread over the 64 lanes
+  for (int e = lane; e < T * (m + 1); e += 64) {
+    const int t = e / (m + 1), j = e - t * (m + 1);
+    const int bi = sel[t];
     const int f = bi / A;
-    const long rowi = n * C + bi;
-    const int code = cand_ids ? cand_ids[rowi] : (bi - f * A);
-    int* ho = hist_out + (n * T + t) * M;
-    const int* hi = hist_in + (n * F + f) * M;
-    for (int j = lane; j < m; j += 64) ho[j] = hi[j];
-    if (lane == 0) ho[m] = code;
-    const float4* src = reinterpret_cast<const float4*>(cand + rowi * D);
-    float4* dst = reinterpret_cast<float4*>(xhat_out + (n * T + t) * D);
-    for (int j = lane; j < D / 4; j += 64) dst[j] = src[j];
+    int v;
+    if (j < m) v = hist_in[(n * F + f) * M + j];
+    else v = cand_ids ? cand_ids[n * C + bi] : (bi - f * A);
+    hist_out[(n * T + t) * M + j] = v;
+  }
+  const int d4 = D / 4;
+  for (int e = lane; e < T * d4; e += 64) {
+    const int t = e / d4, j = e - t * d4;
+    const float4* src = reinterpret_cast<const float4*>(cand + (n * C + sel[t]) * D);
+    reinterpret_cast<float4*>(xhat_out + (n * T + t) * D)[j] = src[j];
   }
 }
 

@@ -152,6 +152,7 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
   // repeat the last group in the MFMA tile and are not selected)
   constexpr int NDB = D / 32, K = NKB * 32, LDK = K + 4;
   __shared__ __attribute__((aligned(16))) float table[4 * 32 * LDK];
+  __shared__ unsigned long long surv_all[4 * SEL_SURV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
   const long g0 = ((long)blockIdx.x * 4 + wave) * gpw;
@@ -237,10 +238,40 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
       *reinterpret_cast<f32x4*>(row + k) = d;
     }
   __builtin_amdgcn_wave_barrier();
-  // Selection: the T rounds of one group are a chain of dependent cross-lane shuffles (latency-bound), so GP
-  // groups are reduced side by side to give the scheduler independent chains to interleave.
-  constexpr int GP = 8;
   const int gend = (int)((G - g0) < gpw ? (G - g0) : gpw);
+  // Selection.  T > 1: one threshold-and-compact selection per group (aux_kernels.hpp, wave_select_smallest), with the
+  // arg-min rounds as the per-group fall-back for massive exact ties.
+  if (T > 1 && T <= 64) {
+    unsigned long long* surv = surv_all + wave * SEL_SURV;
+    for (int gl = 0; gl < gend; ++gl) {
+      float* dg = mytab + gl * LDK;
+      int rank, index;
+      if (wave_select_smallest(dg, K, T, surv, lane, rank, index)) {
+        if (rank >= 0) ids_out[(g0 + gl) * T + rank] = index;
+      } else {
+        for (int t = 0; t < T; ++t) {
+          float bv = __builtin_inff();
+          int bi = 0x7fffffff;
+#pragma unroll
+          for (int k = lane; k < K; k += 64) {
+            const float v = dg[k];
+            const bool take = v < bv;
+            bv = take ? v : bv;
+            bi = take ? k : bi;
+          }
+          wave_argmin(bv, bi);
+          if (bi == 0x7fffffff) bi = 0;
+          if (lane == 0) ids_out[(g0 + gl) * T + t] = bi;
+          if ((bi & 63) == lane) dg[bi] = __builtin_inff();
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    return;
+  }
+  // T == 1 (arg-min: step 0 of a greedy search) or T > 64: rounds of wave arg-min.  The rounds of one group are a chain of
+  // dependent cross-lane shuffles (latency-bound), so GP groups are reduced side by side.
+  constexpr int GP = 8;
   for (int gl0 = 0; gl0 < gend; gl0 += GP) {
     for (int t = 0; t < T; ++t) {
       float bv[GP];

@@ -3,6 +3,7 @@
 // sequence of encode (qinco_inference.py:239-254 + :156-224 / :78-140) and decode (:66-75).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -105,6 +106,7 @@ struct qinco_handle_s {
   // scratch (sized for d.max_batch, A, B)
   int64_t cap_n = 0;
   int cap_A = -1, cap_B = -1;
+  size_t beam_lds_max = 0;   // dynamic LDS already granted to beam_select_kernel
   float* xn = nullptr;
   float* xhat[2] = {nullptr, nullptr};
   int* hist[2] = {nullptr, nullptr};
@@ -839,7 +841,14 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
     if ((rc = launch_mlp(h, a, m, st))) return rc;
     const int C = F * Ae;
     const int T = Fout_cfg < C ? Fout_cfg : C;
-    size_t lds = (size_t)4 * C * sizeof(float);
+    const size_t lds = (size_t)4 * (((C + T + 3) & ~3) + 2 * SEL_SURV) * sizeof(float);
+    if (lds > 160 * 1024)
+      return fail(QINCO_ERR_UNSUPPORTED, "beam_select: %d candidates per vector do not fit the 160 KiB of LDS", C);
+    if (lds > 64 * 1024 && lds > h->beam_lds_max) {   // above the default dynamic-LDS limit: raise it once
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(beam_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+      h->beam_lds_max = lds;
+    }
     hipLaunchKernelGGL(beam_select_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, st, h->dist, h->cand, cand_ids,
                        (long)n, F, Ae, D, T, m, M, h->hist[cur], h->hist[cur ^ 1], h->xhat[cur ^ 1]);
     HIP_TRY(hipGetLastError());
@@ -1184,6 +1193,97 @@ extern "C" int qinco_lut_decode_host(qinco_lut l, const void* codes, int code_dt
   if (flag) {
     HIP_TRY(hipMemset(l->err_flag, 0, sizeof(int)));
     return fail(QINCO_ERR_RANGE, "qinco_lut_decode: a look-up index is outside its table");
+  }
+  return QINCO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device self-test of the in-wave sorting / selection primitives (aux_kernels.hpp)
+// ---------------------------------------------------------------------------------------------
+extern "C" int qinco_selftest(void) {
+  struct Lcg {
+    unsigned long long s;
+    unsigned next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(s >> 33); }
+  } rng{12345};
+  // 1. wave_sort64
+  const int NW = 256;
+  std::vector<unsigned> hin((size_t)NW * 64), hout(hin.size());
+  for (size_t i = 0; i < hin.size(); ++i) hin[i] = (i / 64) % 3 == 0 ? rng.next() % 7 : rng.next();   // every third wave: many duplicates
+  unsigned *din = nullptr, *dout = nullptr;
+  HIP_TRY(hipMalloc(&din, hin.size() * 4));
+  HIP_TRY(hipMalloc(&dout, hin.size() * 4));
+  HIP_TRY(hipMemcpy(din, hin.data(), hin.size() * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(selftest_sort_kernel, dim3(NW), dim3(64), 0, nullptr, din, dout);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(hout.data(), dout, hout.size() * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(din);
+  (void)hipFree(dout);
+  for (int w = 0; w < NW; ++w) {
+    std::vector<unsigned> want(hin.begin() + w * 64, hin.begin() + (w + 1) * 64);
+    std::sort(want.begin(), want.end());
+    for (int l = 0; l < 64; ++l)
+      if (hout[(size_t)w * 64 + l] != want[l])
+        return fail(QINCO_ERR_HIP, "qinco_selftest: wave_sort64 wrong at wave %d lane %d (%u, want %u)", w, l, hout[(size_t)w * 64 + l], want[l]);
+  }
+  // 2. wave_select_smallest: (C, T) pairs, continuous values / heavy ties / NaN and inf
+  const int cases[][2] = {{256, 16}, {256, 32}, {256, 2}, {128, 8}, {512, 32}, {100, 7}, {64, 64}, {2048, 8}, {37, 37}, {8192, 32}, {256, 48}};
+  for (const auto& ct : cases) {
+    const int C = ct[0], T = ct[1], NP = 96;
+    std::vector<float> hd((size_t)NP * C);
+    for (int p = 0; p < NP; ++p)
+      for (int k = 0; k < C; ++k) {
+        float v;
+        const int kind = p % 4;
+        if (kind == 0) v = (float)(rng.next() % 100000) * 1e-3f - 20.f;          // continuous, both signs
+        else if (kind == 1) v = (float)(rng.next() % 40);                         // heavy ties
+        else if (kind == 2) v = (float)(rng.next() % 1000) * 0.5f;                // some ties
+        else {
+          const unsigned r = rng.next() % 50;
+          v = r == 0 ? __builtin_nanf("") : r == 1 ? __builtin_inff() : r == 2 ? -0.f : (float)(rng.next() % 5000) * 1e-2f;
+        }
+        hd[(size_t)p * C + k] = v;
+      }
+    float* dd = nullptr;
+    int *dids = nullptr, *dfb = nullptr;
+    HIP_TRY(hipMalloc(&dd, hd.size() * 4));
+    HIP_TRY(hipMalloc(&dids, (size_t)NP * T * 4));
+    HIP_TRY(hipMalloc(&dfb, NP * 4));
+    HIP_TRY(hipMemcpy(dd, hd.data(), hd.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dids, 0xFF, (size_t)NP * T * 4));
+    const size_t lds = (size_t)(((C + 3) & ~3) + 2 * SEL_SURV) * 4;
+    hipLaunchKernelGGL(selftest_select_kernel, dim3(NP), dim3(64), lds, nullptr, dd, C, T, dids, dfb);
+    HIP_TRY(hipGetLastError());
+    std::vector<int> hids((size_t)NP * T), hfb(NP);
+    HIP_TRY(hipMemcpy(hids.data(), dids, hids.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hfb.data(), dfb, NP * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dd);
+    (void)hipFree(dids);
+    (void)hipFree(dfb);
+    for (int p = 0; p < NP; ++p) {
+      std::vector<int> order(C);
+      for (int k = 0; k < C; ++k) order[k] = k;
+      const float* row = &hd[(size_t)p * C];
+      auto key = [&](int k) -> unsigned long long {   // the device's ordering: NaN last, -0 == +0, ties -> lower index
+        const float v = row[k];
+        unsigned u;
+        if (v != v) u = 0xffffffffu;
+        else {
+          const float z = v + 0.f;
+          std::memcpy(&u, &z, 4);
+          u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        }
+        return ((unsigned long long)u << 32) | (unsigned)k;
+      };
+      std::sort(order.begin(), order.end(), [&](int x, int y) { return key(x) < key(y); });
+      if (hfb[p]) {
+        if (p % 4 == 0) return fail(QINCO_ERR_HIP, "qinco_selftest: selection fell back on continuous data (C=%d, T=%d)", C, T);
+        continue;
+      }
+      for (int t = 0; t < T; ++t)
+        if (hids[(size_t)p * T + t] != order[t])
+          return fail(QINCO_ERR_HIP, "qinco_selftest: wave_select_smallest wrong (C=%d, T=%d, problem %d, rank %d: %d, want %d)", C, T, p, t,
+                      hids[(size_t)p * T + t], order[t]);
+    }
   }
   return QINCO_OK;
 }

@@ -537,3 +537,10 @@ def test_weight_delivery_variants_agree_bitwise(wl, tmp_path):
         diff = int((res[k]["codes"] != base["codes"]).any(axis=1).sum())
         print(f"{wl}: {k} (folded head) vs unfolded: {diff} of {n} code rows differ")
         assert diff <= n // 1000
+
+
+def test_device_selftest_of_sort_and_selection_primitives():
+    """qinco_selftest: wave_sort64 and wave_select_smallest (the threshold-and-compact top-T) against a host sort, on
+    continuous data, heavy ties, NaN / inf, for the (C, T) pairs the table and beam kernels use."""
+    from qinco_amd import _lib
+    _lib.check(_lib.load().qinco_selftest())

@@ -187,6 +187,94 @@ QINCO_DEV bool wave_select_smallest(const float* dv, int C, int T, unsigned long
   return true;
 }
 
+// wave_sort64 of GP independent values, one compare-exchange step at a time across all of them (a dependent DPP chain needs
+// wait states after every step; GP chains interleaved need none)
+template <int K, int J, int GP>
+QINCO_DEV void sel_merge_multi(unsigned (&x)[GP]) {
+#pragma unroll
+  for (int u = 0; u < GP; ++u) x[u] = sel_cmpx<K, J>(x[u]);
+  if constexpr (J > 1) sel_merge_multi<K, J / 2, GP>(x);
+}
+template <int GP>
+QINCO_DEV void wave_sort64_multi(unsigned (&x)[GP]) {
+  sel_merge_multi<2, 1, GP>(x);
+  sel_merge_multi<4, 2, GP>(x);
+  sel_merge_multi<8, 4, GP>(x);
+  sel_merge_multi<16, 8, GP>(x);
+  sel_merge_multi<32, 16, GP>(x);
+  sel_merge_multi<64, 32, GP>(x);
+}
+
+// The same selection for GP groups of 64 * NV distances side by side (rows of an LDS table, `ld` floats apart): one group's
+// selection is a chain of dependent cross-lane steps and VALU -> SALU -> VALU round trips (~3700 cycles alone on a SIMD that
+// holds a single wave), GP independent chains interleave in the instruction stream.  Returns a bit per group: 1 = selected
+// (lanes with rank[u] >= 0 hold an output pair), 0 = fall back to the rounds for that group.
+template <int GP, int NV>
+QINCO_DEV unsigned wave_select_smallest_multi(const float* tab, int ld, int T, unsigned long long* surv, int lane, int (&rank)[GP],
+                                              int (&index)[GP]) {
+  unsigned key[GP][NV], lm[GP], tau[GP];
+  int S[GP];
+#pragma unroll
+  for (int u = 0; u < GP; ++u) {
+    lm[u] = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      key[u][i] = sel_key(tab[u * ld + lane + 64 * i]);
+      lm[u] = umin(lm[u], key[u][i]);
+    }
+  }
+  wave_sort64_multi<GP>(lm);
+#pragma unroll
+  for (int u = 0; u < GP; ++u) tau[u] = (unsigned)__builtin_amdgcn_readlane((int)lm[u], T - 1);
+  unsigned long long mask[GP][NV];
+#pragma unroll
+  for (int u = 0; u < GP; ++u)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) mask[u][i] = __builtin_amdgcn_ballot_w64(key[u][i] <= tau[u]);
+#pragma unroll
+  for (int u = 0; u < GP; ++u) {
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask[u][i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u][i], 0u));
+      if (key[u][i] <= tau[u] && pos < 64) surv[u * SEL_SURV + pos] = ((unsigned long long)key[u][i] << 32) | (unsigned)(lane + 64 * i);
+      base += __builtin_popcountll(mask[u][i]);
+    }
+    S[u] = base;
+  }
+  unsigned ok = 0;
+  int smax = 0;
+#pragma unroll
+  for (int u = 0; u < GP; ++u) {
+    const int s = S[u] < 64 ? S[u] : 64;
+    if (s + lane < SEL_SURV) surv[u * SEL_SURV + s + lane] = ~0ull;   // everything behind the survivors compares as "not smaller"
+    if (S[u] <= 64) ok |= 1u << u;
+    smax = s > smax ? s : smax;
+  }
+  __builtin_amdgcn_wave_barrier();
+  unsigned long long mine[GP];
+  int r[GP];
+#pragma unroll
+  for (int u = 0; u < GP; ++u) {
+    mine[u] = lane < S[u] && lane < 64 ? surv[u * SEL_SURV + lane] : ~0ull;
+    r[u] = 0;
+  }
+  for (int j0 = 0; j0 < smax; j0 += 8) {
+#pragma unroll
+    for (int u = 0; u < GP; ++u)
+#pragma unroll
+      for (int v = 0; v < 8; ++v) r[u] += surv[u * SEL_SURV + j0 + v] < mine[u] ? 1 : 0;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int u = 0; u < GP; ++u) {
+    const bool sel = lane < S[u] && r[u] < T && ((ok >> u) & 1);
+    rank[u] = sel ? r[u] : -1;
+    index[u] = (int)(unsigned)mine[u];
+  }
+  return ok;
+}
+
 // self-test kernels (qinco_selftest): one wave per problem
 __global__ void __launch_bounds__(64) selftest_sort_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out) {
   const int lane = threadIdx.x;

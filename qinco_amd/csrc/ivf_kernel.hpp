@@ -137,22 +137,25 @@ __global__ void ivf_finish_kernel(const unsigned long long* __restrict__ best, l
 
 // ---------------------------------------------------------------------------------------------
 // K1+K2 on the matrix cores: the residual -> codebook table of dist_topk_kernel (aux_kernels.hpp) for K = 32*NKB
-// codewords, evaluated like the IVF table (a wave = 32 groups as B operands, codebook fragments as A operands),
-// written to a wave-private LDS table [32 groups][K (+4 pad)] and reduced by the same T rounds of wave64
-// shuffle arg-min.  r = x - xhat is formed on load (blocks are streamed, so any D fits), |r|^2 on the fly.
-// The VALU version spent 6x longer on the table than on the selection (profiles: 621 us per 65 536 groups).
+// codewords, evaluated like the IVF table (a wave = 32 groups as B operands, codebook fragments as A operands), then the
+// T smallest per group, ascending.  r = x - xhat is formed on load (blocks are streamed, so any D fits), |r|^2 on the fly.
+// The 32 x K tile of a wave goes through a wave-private LDS table in two halves of 16 groups ([16][K + 4] floats): 66.5 KiB
+// per workgroup and <= 256 registers, so that TWO workgroups share a CU -- the table phase (matrix pipe) and the selection
+// phase (VALU / LDS / SALU latency chains) of a wave do not overlap with themselves, only with another wave's.
+// Selection: threshold-and-compact (aux_kernels.hpp, wave_select_smallest_multi), four groups side by side; T = 1 and
+// T > 64 take rounds of wave arg-min.
+// (history: VALU table 621 us per 65 536 groups -> MFMA table + T arg-min rounds 235 us -> this form, profiles/r02_*)
 // ---------------------------------------------------------------------------------------------
 template <int D, int NKB>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xhat, int F,
                       const f32x4* __restrict__ cstream, const float* __restrict__ cnorm, long G, int T,
                       int* __restrict__ ids_out, int gpw) {
-  // gpw = groups per wave (32, or 8 for small launches: the T selection rounds of a wave's groups are serial, so a
-  // launch that cannot fill the chip with 32-group waves is latency-bound -- 200 us for 8192 groups; lanes past gpw
+  // gpw = groups per wave (32, or 8 for small launches, which could not fill the chip with 32-group waves; lanes past gpw
   // repeat the last group in the MFMA tile and are not selected)
-  constexpr int NDB = D / 32, K = NKB * 32, LDK = K + 4;
-  __shared__ __attribute__((aligned(16))) float table[4 * 32 * LDK];
-  __shared__ unsigned long long surv_all[4 * SEL_SURV];
+  constexpr int NDB = D / 32, K = NKB * 32, LDK = K + 4, SGP = 4;
+  __shared__ __attribute__((aligned(16))) float table[4 * 16 * LDK];
+  __shared__ unsigned long long surv_all[4 * SGP * SEL_SURV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
   const long g0 = ((long)blockIdx.x * 4 + wave) * gpw;
@@ -168,10 +171,8 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
   // Codebook fragments in the order they are used (feature block, q, codeword block) through a fenced register ring,
-  // the raw x / xhat rows of the next feature block fetched before the current block's MFMAs.  Without this every one
-  // of the 32 * NDB fragments exposed an L2 round trip to the single wave of its SIMD (rocprofv3: 200 us for ONE
-  // workgroup, of which the MFMAs are 14 us).
-  constexpr int NFR = NDB * 4 * NKB, P = NDB > 8 ? 8 : 16;
+  // the raw x / xhat rows of the next feature block fetched before the current block's MFMAs.
+  constexpr int NFR = NDB * 4 * NKB, P = 8;
   auto frag_ofs = [](int i) { return (((i % NKB) * NDB + i / (4 * NKB)) * 4 + (i / NKB) % 4) * 64; };
   f32x4 ring[P];
 #pragma unroll
@@ -184,7 +185,7 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
   }
   float rn = 0.f;
   static_assert((4 * NKB) % P == 0, "ring slots must not depend on the feature block");
-  constexpr int IB_UNROLL = NDB > 8 ? 1 : NDB;  // wide D: keep the feature-block loop rolled (registers)
+  constexpr int IB_UNROLL = NDB > 2 ? 1 : NDB;  // feature-block loop rolled: 255 registers, no spills (2 waves per SIMD); unrolled it spills and is slower
 #pragma unroll IB_UNROLL
   for (int ib = 0; ib < NDB; ++ib) {
     f32x16 rb;
@@ -224,82 +225,100 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
   }
   static_assert(NFR > 0, "");
   rn += __shfl_xor(rn, 32);
-  float* mytab = table + wave * 32 * LDK;
-  float* row = mytab + j * LDK;
+  // distances in place of the dot products: (|r|^2 + |c|^2) - 2 r.c  (the reference's association, utils.py:336-346)
 #pragma unroll
   for (int cb = 0; cb < NKB; ++cb)
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-      const int k = cb * 32 + 8 * gq + 4 * half;
-      const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + k);
-      f32x4 d;
+      const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + cb * 32 + 8 * gq + 4 * half);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) d[e] = __fsub_rn(__fadd_rn(rn, cn[e]), __fmul_rn(2.f, acc[cb][4 * gq + e]));
-      *reinterpret_cast<f32x4*>(row + k) = d;
+      for (int e = 0; e < 4; ++e) acc[cb][4 * gq + e] = __fsub_rn(__fadd_rn(rn, cn[e]), __fmul_rn(2.f, acc[cb][4 * gq + e]));
     }
-  __builtin_amdgcn_wave_barrier();
+  float* mytab = table + wave * 16 * LDK;
+  unsigned long long* surv = surv_all + wave * SGP * SEL_SURV;
   const int gend = (int)((G - g0) < gpw ? (G - g0) : gpw);
-  // Selection.  T > 1: one threshold-and-compact selection per group (aux_kernels.hpp, wave_select_smallest), with the
-  // arg-min rounds as the per-group fall-back for massive exact ties.
-  if (T > 1 && T <= 64) {
-    unsigned long long* surv = surv_all + wave * SEL_SURV;
-    for (int gl = 0; gl < gend; ++gl) {
-      float* dg = mytab + gl * LDK;
-      int rank, index;
-      if (wave_select_smallest(dg, K, T, surv, lane, rank, index)) {
-        if (rank >= 0) ids_out[(g0 + gl) * T + rank] = index;
-      } else {
-        for (int t = 0; t < T; ++t) {
-          float bv = __builtin_inff();
-          int bi = 0x7fffffff;
+  for (int h = 0; h < 2 && h * 16 < gend; ++h) {
+    // groups h*16 .. h*16+15 of the tile -> table rows 0..15
+    if ((j >> 4) == h) {
+      float* row = mytab + (j & 15) * LDK;
 #pragma unroll
-          for (int k = lane; k < K; k += 64) {
-            const float v = dg[k];
-            const bool take = v < bv;
-            bv = take ? v : bv;
-            bi = take ? k : bi;
+      for (int cb = 0; cb < NKB; ++cb)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 d = {acc[cb][4 * gq], acc[cb][4 * gq + 1], acc[cb][4 * gq + 2], acc[cb][4 * gq + 3]};
+          *reinterpret_cast<f32x4*>(row + cb * 32 + 8 * gq + 4 * half) = d;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int nrow = gend - h * 16 < 16 ? gend - h * 16 : 16;
+    const long gbase = g0 + h * 16;
+    if (T > 1 && T <= 64) {
+      for (int r0 = 0; r0 < nrow; r0 += SGP) {
+        // (rows past nrow hold stale distances of this wave: selected and discarded)
+        int rank[SGP], index[SGP];
+        const unsigned ok = wave_select_smallest_multi<SGP, K / 64>(mytab + r0 * LDK, LDK, T, surv, lane, rank, index);
+#pragma unroll
+        for (int u = 0; u < SGP; ++u) {
+          const int r = r0 + u;
+          if (r >= nrow) break;
+          if ((ok >> u) & 1) {
+            if (rank[u] >= 0) ids_out[(gbase + r) * T + rank[u]] = index[u];
+            continue;
           }
-          wave_argmin(bv, bi);
-          if (bi == 0x7fffffff) bi = 0;
-          if (lane == 0) ids_out[(g0 + gl) * T + t] = bi;
-          if ((bi & 63) == lane) dg[bi] = __builtin_inff();
+          float* dg = mytab + r * LDK;   // massive exact ties: the arg-min rounds
+          for (int t = 0; t < T; ++t) {
+            float bv = __builtin_inff();
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int k = lane; k < K; k += 64) {
+              const float v = dg[k];
+              const bool take = v < bv;
+              bv = take ? v : bv;
+              bi = take ? k : bi;
+            }
+            wave_argmin(bv, bi);
+            if (bi == 0x7fffffff) bi = 0;
+            if (lane == 0) ids_out[(gbase + r) * T + t] = bi;
+            if ((bi & 63) == lane) dg[bi] = __builtin_inff();
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+    } else {
+      // T == 1 (arg-min: step 0 of a greedy search) or T > 64: rounds of wave arg-min.  The rounds of one group are a chain
+      // of dependent cross-lane shuffles (latency-bound), so GP groups are reduced side by side.
+      constexpr int GP = 8;
+      for (int r0 = 0; r0 < nrow; r0 += GP) {
+        for (int t = 0; t < T; ++t) {
+          float bv[GP];
+          int bi[GP];
+#pragma unroll
+          for (int u = 0; u < GP; ++u) {
+            const float* dg = mytab + (r0 + u < 16 ? r0 + u : 15) * LDK;
+            bv[u] = __builtin_inff();
+            bi[u] = 0x7fffffff;
+#pragma unroll
+            for (int k = lane; k < K; k += 64) {  // k ascends: strict < keeps the lowest index
+              const float v = dg[k];
+              const bool take = v < bv[u];
+              bv[u] = take ? v : bv[u];
+              bi[u] = take ? k : bi[u];
+            }
+          }
+          wave_argmin_u<GP>(bv, bi);  // GP interleaved integer-min chains: no branch, no SGPR round trip
+#pragma unroll
+          for (int u = 0; u < GP; ++u) {
+            if (r0 + u < nrow) {
+              int b = bi[u] == 0x7fffffff ? 0 : bi[u];
+              if (lane == 0) ids_out[(gbase + r0 + u) * T + t] = b;
+              if ((b & 63) == lane) mytab[(r0 + u) * LDK + b] = __builtin_inff();
+            }
+          }
           __builtin_amdgcn_wave_barrier();
         }
       }
     }
-    return;
-  }
-  // T == 1 (arg-min: step 0 of a greedy search) or T > 64: rounds of wave arg-min.  The rounds of one group are a chain of
-  // dependent cross-lane shuffles (latency-bound), so GP groups are reduced side by side.
-  constexpr int GP = 8;
-  for (int gl0 = 0; gl0 < gend; gl0 += GP) {
-    for (int t = 0; t < T; ++t) {
-      float bv[GP];
-      int bi[GP];
-#pragma unroll
-      for (int u = 0; u < GP; ++u) {
-        const float* dg = mytab + (gl0 + u < 32 ? gl0 + u : 31) * LDK;
-        bv[u] = __builtin_inff();
-        bi[u] = 0x7fffffff;
-#pragma unroll
-        for (int k = lane; k < K; k += 64) {  // k ascends: strict < keeps the lowest index
-          const float v = dg[k];
-          const bool take = v < bv[u];
-          bv[u] = take ? v : bv[u];
-          bi[u] = take ? k : bi[u];
-        }
-      }
-      wave_argmin_u<GP>(bv, bi);  // GP interleaved integer-min chains: no branch, no SGPR round trip
-#pragma unroll
-      for (int u = 0; u < GP; ++u) {
-        if (gl0 + u < gend) {
-          int b = bi[u] == 0x7fffffff ? 0 : bi[u];
-          if (lane == 0) ids_out[(g0 + gl0 + u) * T + t] = b;
-          if ((b & 63) == lane) mytab[(gl0 + u) * LDK + b] = __builtin_inff();
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
+    __builtin_amdgcn_wave_barrier();   // the next half overwrites the rows
   }
 }
 

@@ -21,7 +21,7 @@ static unsigned exclusive_lds() {  // shared ring: 48 KiB static + 36 = 84 > 80.
     const char* e = getenv("QINCO_RING_PAD_KIB");
     return (unsigned)((e ? atoi(e) : 36) * 1024);
   }();
-  return (QVAR & 64) ? pad : 0u;
+  return ((QVAR & 64) && !(QVAR & 256)) ? pad : 0u;   // OCC2 instances are meant to share a CU
 }
 #define kExclusiveLds exclusive_lds()
 

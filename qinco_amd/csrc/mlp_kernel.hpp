@@ -29,6 +29,10 @@
 //             qinco_create), W_cat[:, De:] xhat depends only on the (vector, beam) group (U, one small MFMA GEMM per
 //             step: xproj_kernel).  The kernel starts from z = T[cid] + U[group]: -4.9 % MFMA work at C2.
 //             Same real-number result as QConcat.forward; the fp32 association differs ((b + Wz z) + Wx xhat).
+//  256 OCC2   two workgroups per CU (launch bounds (256, 2): <= 256 registers per lane): one chain accumulator and eager chain
+//             epilogues instead of the one-chain-late plan (two waves per SIMD fill each other's pipe drains), so that a
+//             wave's prologue gathers and epilogue stores run under the other wave's MFMAs.  For short MLPs (qinco2-S, QINCo1:
+//             De = 128, Dh = 256), where those phases are 24 % of a tile's time (profiles/r02_timeline.jsonl).
 //   32 FOLD2  (with FOLD) the first FFN block's up-projection is linear in z = T + U as well:
 //             W_up[0] z = P[cid] + Q[group] with P = W_up[0] T (table) and Q = W_up[0] U (same xproj launch), so the
 //             kernel starts with y = relu(P[cid] + Q[group]) and the first down-projection: -2.9 % more at C2, -20 %
@@ -94,9 +98,10 @@ QINCO_INL void pin_v(f32x16& v) { asm volatile("" : "+v"(v)); }
 QINCO_INL void pin_a(f32x16& v) { asm volatile("" : "+a"(v)); }
 
 template <int D, int DE, int DH, int P, int VAR>
-__global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
+__global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a) {
   constexpr bool FOLD = (VAR & 16) != 0;
   constexpr bool FOLD2 = (VAR & 32) != 0;
+  constexpr bool OCC2 = (VAR & 256) != 0;
   static_assert(!FOLD2 || (FOLD && (VAR & 8)), "FOLD2 needs FOLD and the pinned plan");
   constexpr StreamDims SL = stream_dims(D, DE, DH, P, FOLD, FOLD2);
   constexpr int NDB = SL.NDB, NEB = SL.NEB, NHB = SL.NHB;
@@ -105,7 +110,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   constexpr bool LDSR = (VAR & 4) != 0;
   constexpr bool PINNED = (VAR & 8) != 0;
   constexpr bool SHR = (VAR & 64) != 0;
-  static_assert((VAR & ~(4 | 8 | 16 | 32 | 64)) == 0, "unknown VAR bits");
+  static_assert((VAR & ~(4 | 8 | 16 | 32 | 64 | 256)) == 0, "unknown VAR bits");
+  static_assert(!OCC2 || (VAR & 8), "OCC2 is a form of the pinned plan");
   static_assert(!SHR || (LDSR && P % 12 == 0 && P / 4 >= 5), "shared ring: P multiple of 12 (3 register sets, 4 issuers)");
   static_assert(!LDSR || SHR || (P % 3 == 0 && P >= 6 && P <= 39), "per-wave LDS rings: 4 x P KiB must fit 160 KiB");
 
@@ -119,6 +125,14 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
   long row = tile * 32 + j;
   const bool valid = row < a.R;
   if (!valid) row = a.R - 1;
+#ifdef QINCO_TIMELINE
+  auto stamp = [&](int i) QINCO_LAMBDA {
+    if (a.timeline && lane == 0) a.timeline[tile * 8 + i] = __builtin_readcyclecounter();
+  };
+  stamp(0);
+#else
+  auto stamp = [](int) QINCO_LAMBDA {};
+#endif
   const long g = row / a.A;
   const int cid = a.cand_ids ? a.cand_ids[row] : (int)(row - g * a.A);
   const float* cptr = a.codebook + (long)cid * D + half * 4;
@@ -174,6 +188,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
 #pragma unroll
     for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
   }
+  stamp(1);   // ring prologue done (first fragments landed, first barrier passed)
   auto take = [&]<int T>() QINCO_LAMBDA -> f32x4 {
     if constexpr (SHR) {
       // Before fragment T = 4g every wave has issued g + P/4 - 1 DMAs; "<= P/4 - 3 outstanding" = its first g + 2
@@ -280,6 +295,14 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = z[ob] + y[ob]; });
   }
 
+#ifdef QINCO_TIMELINE
+  {   // all head operands have arrived (forces the waits here, where the production kernel lets them overlap the first chain)
+    float chk = 0.f;
+    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { chk += z[ob][0]; });
+    if (chk == 123.4567f) a.cand_out[0] = chk;
+  }
+#endif
+  stamp(2);   // z (and y) assembled
   // ---- D: L residual FFN blocks: z = z + W_down . relu(W_up . z)   (QBlockFFN.forward) ---------
   if constexpr (PINNED) {
     // Register-file plan (the compiler is told, not asked): z lives in VGPRs (B operand of the up-projection,
@@ -292,6 +315,20 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA { pin_v(z[ob]); });
     f32x16 t[2];
     auto up_phase = [&]() QINCO_LAMBDA {
+      if constexpr (OCC2) {   // one accumulator, epilogue at the chain end
+        static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
+          t[0] = zero16();
+          static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
+            static_for<4>([&]<int q>() QINCO_LAMBDA { fragmm.template operator()<(ob * NEB + ib) * 4 + q, q>(t[0], z[ib], noop); });
+          });
+          relu16(t[0]);
+          y[ob] = t[0];
+          pin_a(y[ob]);
+        });
+        skip_pad.template operator()<NHB * NEB * 4, SL.T_UP>();
+        wp += SL.T_UP * 64;
+        return;
+      }
       static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
         t[ob & 1] = zero16();
         static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
@@ -315,6 +352,19 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
       wp += SL.T_UP * 64;
     };
     auto down_phase = [&]() QINCO_LAMBDA {
+      if constexpr (OCC2) {
+        static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+          t[0] = zero16();
+          static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
+            static_for<4>([&]<int q>() QINCO_LAMBDA { fragmm.template operator()<(ob * NHB + ib) * 4 + q, q>(t[0], y[ib], noop); });
+          });
+          z[ob] = z[ob] + t[0];
+          pin_v(z[ob]);
+        });
+        skip_pad.template operator()<NEB * NHB * 4, SL.T_DOWN>();
+        wp += SL.T_DOWN * 64;
+        return;
+      }
       static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
         t[ob & 1] = zero16();
         static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
@@ -371,6 +421,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     }
   }
 
+  stamp(3);   // FFN blocks done
   // ---- E: out_proj + epilogue: cand = (out + coeff*c) + xhat ; dist = |x|^2 + |cand|^2 - 2 x.cand
   const long n = g / a.F;
   const float* xptr = a.x ? a.x + n * D + half * 4 : nullptr;
@@ -417,8 +468,10 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(MlpArgs a) {
     xn += __shfl_xor(xn, 32);
     if (valid && half == 0) a.dist_out[row] = (xn + s2) - 2.f * sx;
   }
+  stamp(4);   // epilogue issued
   // no LDS-DMA may be in flight when the wave ends (its LDS could be handed to the next workgroup)
   if constexpr (LDSR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(5);   // stores / tail DMAs retired
 }
 
 // U[g] = W_cat[:, De:] . xhat_g for every (vector, beam) group (FOLD).  Same transposed-MFMA form: a wave keeps its 32

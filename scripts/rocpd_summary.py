@@ -20,6 +20,14 @@ def main(db, prefix):
         for name, calls, tot, avg, pct in rows:
             w.writerow([name, calls, f"{tot:.3f}", f"{avg:.3f}", f"{pct:.4f}"])
     tables = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    if "kernels" in tables:   # the same kernel at different launch sizes: one line per (kernel, grid)
+        rows = cur.execute("select name, grid_x, grid_y, count(*), avg(duration), min(duration), max(duration) from kernels "
+                           "group by name, grid_x, grid_y order by sum(duration) desc").fetchall()
+        with open(prefix + "_by_grid.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "grid_x_threads", "grid_y", "calls", "avg_us", "min_us", "max_us"])
+            for name, gx, gy, n, avg, mn, mx in rows:
+                w.writerow([name, gx, gy, n, f"{avg / 1e3:.3f}", f"{mn / 1e3:.3f}", f"{mx / 1e3:.3f}"])
     if "counters_collection" not in tables:
         return
     acc = defaultdict(lambda: defaultdict(float))     # (kernel, dispatch) -> counter -> summed value

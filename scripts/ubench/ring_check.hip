@@ -30,11 +30,16 @@ struct Args {
   float* out;            // epilogue: stores
   int epilogue;
   int mfma;              // MFMAs per fragment (0 or 4)
+  const unsigned* probe; // PROBE: cold rows loaded into VGPRs by ordinary loads while LDS-DMAs are in flight (value = its own index)
+  unsigned* probe_bad;   // PROBE: [count of wrong probe values]
 };
 
 // LIVE = fragments of each 48-fragment section that are consumed (the rest are "padding": their barriers / DMAs happen, the
 // LDS reads are dead code, exactly like skip_pad in the real kernels)
-template <int LIVE, int CONSERVATIVE>
+// PROBE: an ordinary global load is issued BEFORE the prologue DMAs (like cand_ids[row] in the real kernels) and one per section in
+// the middle of the stream (like the codeword / xhat block prefetches); hipcc waits for them with a COUNTED vmcnt that assumes
+// LDS-DMA loads and VGPR loads complete in issue order.
+template <int LIVE, int CONSERVATIVE, int PROBE = 0>
 __global__ void __launch_bounds__(256, 1) ring_check(Args a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -54,11 +59,15 @@ __global__ void __launch_bounds__(256, 1) ring_check(Args a) {
     else __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
     asm volatile("" ::: "memory");
   };
+  const long gw = (long)blockIdx.x * 4 + wave;
+  unsigned probe0 = 0, pbad = 0;
+  if constexpr (PROBE) probe0 = a.probe[gw * 64 * 64 + lane * 64];   // one cold 256-byte-strided line per lane
   static_for<P / 4 - 1>([&]<int i>() LAMBDA { dma.template operator()<4 * i>(); });
   wait_vm.template operator()<P / 4 - 2>();
   __builtin_amdgcn_s_barrier();
   ring[0] = myring[lane];
   ring[1] = myring[64 + lane];
+  if constexpr (PROBE) pbad += probe0 != (unsigned)(gw * 64 * 64 + lane * 64);
   auto take = [&]<int T>() LAMBDA -> u32x4 {
     if constexpr ((T & 3) == 0) {
       wait_vm.template operator()<P / 4 - 3>();
@@ -74,7 +83,10 @@ __global__ void __launch_bounds__(256, 1) ring_check(Args a) {
   const float bval = 1.0f + lane * 1e-3f;
 #pragma unroll 1
   for (int sec = 0; sec < a.nsec; ++sec) {
+    unsigned probe1 = 0;
     static_for<P>([&]<int T>() LAMBDA {
+      if constexpr (PROBE && T == 2) probe1 = a.probe[gw * 64 * 64 + lane * 64 + 1 + sec];   // issued mid-stream ...
+      if constexpr (PROBE && T == 7) pbad += probe1 != (unsigned)(gw * 64 * 64 + lane * 64 + 1 + sec);   // ... used 5 fragments later
       const u32x4 w = take.template operator()<T>();
       if constexpr (T < LIVE) {
         const unsigned f = (unsigned)(sec * P + T);
@@ -108,6 +120,9 @@ __global__ void __launch_bounds__(256, 1) ring_check(Args a) {
     a.out[0] = acc[1];
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (PROBE) {
+    if (pbad) atomicAdd(a.probe_bad, pbad);
+  }
   // one record per lane that saw something wrong (lane 0 otherwise)
   unsigned smid;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(smid));
@@ -128,13 +143,14 @@ __global__ void __launch_bounds__(256, 1) ring_check(Args a) {
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-template <int LIVE, int CONS>
+template <int LIVE, int CONS, int PROBE = 0>
 static void run(const char* name, Args a, int grid, int pad_kib, unsigned* d_rec, int reps) {
   const size_t nw = (size_t)grid * 4;
   std::vector<unsigned> rec(nw * 8);
   for (int r = 0; r < reps; ++r) {
     CK(hipMemset(d_rec, 0, nw * 8 * sizeof(unsigned)));
-    hipLaunchKernelGGL((ring_check<LIVE, CONS>), dim3(grid), dim3(256), (size_t)pad_kib * 1024, 0, a);
+    if (PROBE) CK(hipMemset(a.probe_bad, 0, 4));
+    hipLaunchKernelGGL((ring_check<LIVE, CONS, PROBE>), dim3(grid), dim3(256), (size_t)pad_kib * 1024, 0, a);
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(rec.data(), d_rec, nw * 8 * sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -154,8 +170,10 @@ static void run(const char* name, Args a, int grid, int pad_kib, unsigned* d_rec
         shown++;
       }
     }
-    printf("%-44s grid %5d pad %2d KiB live %2d mfma %d epi %d  rep %d: %ld bad waves of %zu, %ld bad fragments\n", name, grid, pad_kib,
-           LIVE, a.mfma, a.epilogue, r, bad_waves, nw, bad_frags);
+    unsigned pb = 0;
+    if (PROBE) CK(hipMemcpy(&pb, a.probe_bad, 4, hipMemcpyDeviceToHost));
+    printf("%-44s grid %5d pad %2d KiB live %2d mfma %d epi %d  rep %d: %ld bad waves of %zu, %ld bad fragments, %u bad probe values\n", name,
+           grid, pad_kib, LIVE, a.mfma, a.epilogue, r, bad_waves, nw, bad_frags, pb);
   }
 }
 
@@ -186,7 +204,24 @@ int main(int argc, char** argv) {
   a.rec = d_rec;
   a.x = d_x;
   a.out = d_out;
+  {   // probe rows: value = own index; 64 * 64 words per wave (16 KiB), so every load is a cold line
+    const size_t np = (size_t)grid * 4 * 64 * 64;
+    std::vector<unsigned> hp(np);
+    for (size_t i = 0; i < np; ++i) hp[i] = (unsigned)i;
+    unsigned *d_probe, *d_pb;
+    CK(hipMalloc(&d_probe, np * 4));
+    CK(hipMemcpy(d_probe, hp.data(), np * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_pb, 4));
+    a.probe = d_probe;
+    a.probe_bad = d_pb;
+  }
   for (int pad : {36, 24, 0}) {
+    a.mfma = 4;
+    a.epilogue = 1;
+    run<48, 0, 1>("PROBE: VGPR loads among the DMAs, all live", a, grid, pad, d_rec, 3);
+    run<8, 0, 1>("PROBE: VGPR loads among the DMAs, 8 live", a, grid, pad, d_rec, 3);
+    a.mfma = 0;
+    run<8, 0, 1>("PROBE: VGPR loads among the DMAs, 8 live", a, grid, pad, d_rec, 3);
     for (int mfma : {4, 0})
       for (int epi : {1, 0}) {
         a.mfma = mfma;

@@ -69,7 +69,10 @@ def cpu_baseline(cfg, sd, budget_s: float = 20.0, chunk: int = 1024):
     import torch
     from oracle.qinco_oracle import OracleQINCo
     from qinco_amd import synth_vectors
-    threads = int(torch.get_num_threads())
+    # The reference's own CPU protocol runs 32 ATen threads (qinco_tasks.py:492).  On this box (128 cores) more threads are
+    # slower: 16 / 32 / 64 / 128 threads gave 39 / 41 / 33 / 20 vectors/s at batch 1024 (profiles/r02_cpu_sweep.jsonl).
+    threads = min(32, int(torch.get_num_threads()))
+    torch.set_num_threads(threads)
     oracle = OracleQINCo.from_config(cfg, sd, backend="torch")
     x = synth_vectors(cfg, sd, 16 * chunk, seed=4242)
     oracle(x[:64], step="encode")  # warm-up
@@ -85,7 +88,8 @@ def cpu_baseline(cfg, sd, budget_s: float = 20.0, chunk: int = 1024):
             "gflops": v * cfg.encode_flops_per_vector() / 1e9,
             "reference_over_port_in_build_container": REF_OVER_PORT_CONTAINER,
             "sample": f"{done} vectors of the same workload in {dt:.1f} s (oracle restatement, codeword MLP on torch CPU "
-                      f"fp32 ops, batches of {chunk}, {threads} ATen threads of {os.cpu_count()} logical cores)"}
+                      f"fp32 ops, batches of {chunk} like qinco_cfg.yaml:38, {threads} ATen threads like qinco_tasks.py:492, "
+                      f"{os.cpu_count()} logical cores on the box)"}
 
 
 def _free_port() -> int:

@@ -115,6 +115,10 @@ BASELINE_CONFIGS = {
     # the smaller presets of the reference (config/model_args/qinco2-S.yaml, qinco2-M.yaml) on BigANN-shaped data
     "S": preset("qinco2-S", D=128, M=8, B=8),
     "M": preset("qinco2-M", D=128, M=8, B=8),
+    # qinco2-S on the other datasets' dimensions (Deep1B 96, FB-ssnpp 256, Contriever 768: in/out projections)
+    "S_d96": preset("qinco2-S", D=96, M=8, B=8),
+    "S_d256": preset("qinco2-S", D=256, M=8, B=8),
+    "S_d768": preset("qinco2-S", D=768, M=8, B=8),
     # QINCo1 on 768-d data (De = D = 768): the 16-row tile kernel (csrc/mlp16_kernel.hpp)
     "Q1_768": preset("qinco1", D=768, M=8),
 }

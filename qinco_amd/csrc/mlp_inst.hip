@@ -8,20 +8,23 @@
 #define QINCO_CAT_(a, b, c, d, e, f) a##b##_##c##_##d##_##e##_##f
 #define QINCO_CAT(a, b, c, d, e, f) QINCO_CAT_(a, b, c, d, e, f)
 
-// The kernels that stream weights through the LDS-DMA ring run ONE workgroup per CU: the launch asks for enough extra
-// dynamic LDS that two workgroups cannot share a CU's 160 KiB.  The production shapes are exclusive anyway (512
-// registers per lane), but with small models the 16-row kernel fits 3 workgroups per CU, and then single waves read
-// wrong weight fragments now and then (about 1 wave in 100 at 1500 workgroups; deterministic and exact with one
-// workgroup per CU; fully conservative waits -- vmcnt(0) + lgkmcnt(0) before every ring barrier -- do not cure it, so
-// it is not the ring's landing / overwrite protocol; waiting for one more landed group than the protocol needs does not
-// cure it either, so it is not a lag between vmcnt and LDS visibility).  Root cause not identified; the padding costs
-// nothing.
-static unsigned exclusive_lds() {  // shared ring: 48 KiB static + 36 = 84 > 80.  QINCO_RING_PAD_KIB: experiments only
-  static const unsigned pad = [] {
+// Co-residency of the shared-ring kernels.  With small models the 16-row kernel (mlp16_kernel.hpp) fits 3 workgroups per CU, and
+// then single waves produce wrong rows now and then (about 1 wave in 100 at 1500 workgroups; exact and deterministic with
+// one workgroup per CU).  Round-2 findings (scripts/ubench/ring_check.hip, scripts/exp_coresidency.py): the ring
+// itself delivers the right bytes at 1-3 workgroups per CU, VGPR loads issued among the LDS-DMAs retire in order, and the
+// 32-row kernels are exact at 2-3 workgroups per CU -- so only the 16-row kernel keeps the padding (its one production
+// shape, De = D = 768, is exclusive by registers anyway).
+static unsigned exclusive_lds() {
+  // 16-row kernel: 48 KiB static + 36 = 84 > 80 -> one workgroup per CU.  The 32-row ring kernels share a CU freely (ring
+  // checker, scripts/exp_coresidency.py and the bitwise variant tests at 2-3 workgroups per CU are clean).
+  // QINCO_RING_PAD_KIB (experiments) overrides the padding of every shared-ring kernel.
+  static const int env = [] {
     const char* e = getenv("QINCO_RING_PAD_KIB");
-    return (unsigned)((e ? atoi(e) : 36) * 1024);
+    return e ? atoi(e) : -1;
   }();
-  return ((QVAR & 64) && !(QVAR & 256)) ? pad : 0u;   // OCC2 instances are meant to share a CU
+  if (!(QVAR & 64)) return 0u;
+  if (env >= 0) return (unsigned)env * 1024u;
+  return (QVAR & 128) ? 36u * 1024u : 0u;
 }
 #define kExclusiveLds exclusive_lds()
 

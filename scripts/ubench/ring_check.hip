@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <utility>
 #include <vector>
 
@@ -32,6 +33,7 @@ struct Args {
   int mfma;              // MFMAs per fragment (0 or 4)
   const unsigned* probe; // PROBE: cold rows loaded into VGPRs by ordinary loads while LDS-DMAs are in flight (value = its own index)
   unsigned* probe_bad;   // PROBE: [count of wrong probe values]
+  f32x4* accout;         // per lane: the MFMA accumulator at the end (every wave computes the same chain -> all waves must agree)
 };
 
 // LIVE = fragments of each 48-fragment section that are consumed (the rest are "padding": their barriers / DMAs happen, the
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(256, 1) ring_check(Args a) {
         }
         if (a.mfma)
           static_for<4>([&]<int e>() LAMBDA {
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w[e] & 0x3fffffu), bval, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(w[e] & 0xffffu) * 0.001f + 1.0f, bval, acc, 0, 0, 0);
           });
       }
     });
@@ -119,6 +121,7 @@ __global__ void __launch_bounds__(256, 1) ring_check(Args a) {
   } else if (a.mfma && acc[0] == 123.456f) {
     a.out[0] = acc[1];
   }
+  if (a.accout) a.accout[((long)blockIdx.x * 4 + wave) * 64 + lane] = acc;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (PROBE) {
     if (pbad) atomicAdd(a.probe_bad, pbad);
@@ -172,8 +175,16 @@ static void run(const char* name, Args a, int grid, int pad_kib, unsigned* d_rec
     }
     unsigned pb = 0;
     if (PROBE) CK(hipMemcpy(&pb, a.probe_bad, 4, hipMemcpyDeviceToHost));
-    printf("%-44s grid %5d pad %2d KiB live %2d mfma %d epi %d  rep %d: %ld bad waves of %zu, %ld bad fragments, %u bad probe values\n", name,
-           grid, pad_kib, LIVE, a.mfma, a.epilogue, r, bad_waves, nw, bad_frags, pb);
+    long acc_bad = -1;
+    if (a.accout && a.mfma) {   // the accumulators of all waves must be bit-equal (same fragments, same B operand per lane)
+      std::vector<float> ha(nw * 64 * 4);
+      CK(hipMemcpy(ha.data(), a.accout, ha.size() * 4, hipMemcpyDeviceToHost));
+      acc_bad = 0;
+      for (size_t w = 1; w < nw; ++w)
+        if (memcmp(&ha[w * 256], &ha[0], 1024) != 0) acc_bad++;
+    }
+    printf("%-44s grid %5d pad %2d KiB live %2d mfma %d epi %d  rep %d: %ld bad waves of %zu, %ld bad fragments, %u bad probe values, %ld waves with a different MFMA result\n", name,
+           grid, pad_kib, LIVE, a.mfma, a.epilogue, r, bad_waves, nw, bad_frags, pb, acc_bad);
   }
 }
 
@@ -198,12 +209,15 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_x, (size_t)grid * 64 * 32 * 4));
   CK(hipMemset(d_x, 0, (size_t)grid * 64 * 32 * 4));
   CK(hipMalloc(&d_out, (size_t)grid * 64 * 33 * 4));
+  f32x4* d_acc;
+  CK(hipMalloc(&d_acc, (size_t)grid * 4 * 64 * 16));
   Args a{};
   a.stream = reinterpret_cast<const u32x4*>(d_stream);
   a.nsec = nsec;
   a.rec = d_rec;
   a.x = d_x;
   a.out = d_out;
+  a.accout = d_acc;
   {   // probe rows: value = own index; 64 * 64 words per wave (16 KiB), so every load is a cold line
     const size_t np = (size_t)grid * 4 * 64 * 64;
     std::vector<unsigned> hp(np);

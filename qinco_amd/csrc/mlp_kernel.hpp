@@ -230,6 +230,10 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
 
   if constexpr (FOLD) {
     // ---- A-C folded: z = T[cid] + U[group] -----------------------------------------------------------
+    // (hipcc turns these gathers into batches of 8 loads drained by vmcnt(0): 5 exposed round trips per tile with 288
+    // registers, 12 under OCC2's 128-VGPR budget -- 74 k of a short-MLP tile's 226 k cycles, profiles/r02_timeline.jsonl.
+    // Hand-pipelined orders -- one block ahead; all table rows first, straight into z / y's AGPRs -- spill 74-136 registers
+    // under OCC2 and were dropped.)
     const float* tptr = a.ttab + (long)cid * DE + half * 4;
     const float* uptr = a.uproj + g * DE + half * 4;
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = load_block(tptr + ob * 32) + load_block(uptr + ob * 32); });

@@ -87,6 +87,11 @@ struct qinco_handle_s {
   float* uproj = nullptr;      // (max_batch * B, De [+ Dh]) scratch: U_g = W_cat[:, De:] xhat_g  [then Q_g = W_up[0] U_g]
   float* duproj = nullptr;     // decode counterpart (dec_cap, De [+ Dh])
   std::vector<f32x4*> wstream;
+  // decode runs one row per group: nothing to share, so the folded head only adds the xproj launch and the U / Q round trip
+  // through HBM.  When the shape has an un-folded instance, decode uses it with its own (complete) weight stream.
+  const MlpInstance* dec_inst = nullptr;
+  StreamDims dec_sd{};
+  std::vector<f32x4*> dec_wstream;
   int* kvals = nullptr;
   int* err_flag = nullptr;
   // IVF step 0
@@ -458,7 +463,7 @@ static int ensure_decode_scratch(qinco_handle_s* h, int64_t n) {
   for (int i = 0; i < 2; ++i)
     if ((rc = dev_alloc(h, &h->dxhat[i], (size_t)want * h->d.D))) return rc;
   if ((rc = dev_alloc(h, &h->codes_t, (size_t)want * h->d.M))) return rc;
-  if (h->fold && (rc = dev_alloc(h, &h->duproj, (size_t)want * (h->d.De + (h->fold2 ? h->d.Dh : 0))))) return rc;
+  if (h->fold && !h->dec_inst && (rc = dev_alloc(h, &h->duproj, (size_t)want * (h->d.De + (h->fold2 ? h->d.Dh : 0))))) return rc;
   h->dec_cap = want;
   return 0;
 }
@@ -518,6 +523,13 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   h->fold2 = fn && (fn->var & 32);
   const bool tile16 = fn && (fn->var & 128);
   h->sd = stream_dims(d.D, d.De, d.Dh, kRing, h->fold, h->fold2, tile16 ? 16 : 32);
+  if (h->fold && !getenv("QINCO_DECODE_FOLDED")) {
+    const MlpInstance* di = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~(16 | 32));
+    if (di && !(di->var & (16 | 32 | 128)) && di->P == fn->P) {
+      h->dec_inst = di;
+      h->dec_sd = stream_dims(d.D, d.De, d.Dh, di->P, false, false, 32);
+    }
+  }
   int rc = 0;
   auto bail = [&](int code) {
     qinco_destroy(h);
@@ -531,6 +543,7 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   h->cnorm.assign(d.M, nullptr);
   h->sub_cnorm.assign(d.M, nullptr);
   h->wstream.assign(d.M, nullptr);
+  h->dec_wstream.assign(d.M, nullptr);
   h->cb_stream.assign(d.M, nullptr);
   h->sub_stream.assign(d.M, nullptr);
   h->ttab.assign(d.M, nullptr);
@@ -602,6 +615,24 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
     float* ds = nullptr;
     if ((rc = upload(h, &ds, s.data(), s.size()))) return bail(rc);
     h->wstream[m] = reinterpret_cast<f32x4*>(ds);
+    if (h->dec_inst) {   // the complete stream (in_proj, bias, concat, every FFN block, out_proj) for the un-folded decode kernel
+      const StreamDims& ds_ = h->dec_sd;
+      std::vector<float> t;
+      t.reserve((size_t)(ds_.total(d.L) + kRing) * 256);
+      if (ds_.PROJ) pack_kouter(t, w->in_proj[m], d.De, d.D, ds_.T_IN);
+      pack_bias(t, w->cat_b[m], d.De, ds_.T_BIAS);
+      pack_kouter(t, w->cat_w[m], d.De, d.De + d.D, ds_.T_CAT);
+      for (int l = 0; l < d.L; ++l) {
+        pack_obouter(t, w->up[(size_t)m * d.L + l], d.Dh, d.De, ds_.T_UP);
+        pack_obouter(t, w->down[(size_t)m * d.L + l], d.De, d.Dh, ds_.T_DOWN);
+      }
+      if (ds_.PROJ) pack_obouter(t, w->out_proj[m], d.D, d.De, ds_.T_OUT);
+      if ((long)(t.size() / 256) != ds_.total(d.L)) return bail(fail(QINCO_ERR_INVALID, "internal: decode stream size mismatch"));
+      t.resize(t.size() + (size_t)kRing * 256, 0.f);
+      float* dt = nullptr;
+      if ((rc = upload(h, &dt, t.data(), t.size()))) return bail(rc);
+      h->dec_wstream[m] = reinterpret_cast<f32x4*>(dt);
+    }
   }
   if ((rc = ensure_scratch(h))) return bail(rc);
   *out = h;
@@ -648,7 +679,8 @@ static unsigned ew_grid(long total) {
 
 // One step's fused MLP over a.R rows.  FOLD: a.uproj names the scratch for U (encode: h->uproj, decode: h->duproj);
 // it is filled here by xproj_kernel for the R/A groups of this launch, and T comes from the step's table.
-static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st) {
+static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool decode = false) {
+  const bool unfolded = decode && h->dec_inst;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->prof) {   // the bracket covers xproj + mlp: all the work the algorithmic FLOP count stands for
     if (h->ev_used == h->ev_pool.size()) {
@@ -662,7 +694,8 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st) {
     h->ev_used++;
     HIP_TRY(hipEventRecord(e0, st));
   }
-  if (h->fold) {
+  if (unfolded) a.wstream = h->dec_wstream[m];
+  if (h->fold && !unfolded) {
     XprojArgs xa{};
     xa.wx = h->wx_stream[m];
     xa.xhat = a.xhat;
@@ -690,7 +723,7 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st) {
     a.timeline = h->tl;
   }
 #endif
-  HIP_TRY(h->inst->fn(&a, st));
+  HIP_TRY((unfolded ? h->dec_inst : h->inst)->fn(&a, st));
   if (h->prof) {
     HIP_TRY(hipEventRecord(e1, st));
     h->prof_flops += (double)a.R * mlp_flops_per_row(h->d);
@@ -942,7 +975,7 @@ static int decode_chunk(qinco_handle_s* h, const void* codes, int code_dtype, in
     a.dist_out = nullptr;
     a.add_c = d.qinco1_mode ? 0 : 1;
     a.uproj = h->duproj;
-    int rc = launch_mlp(h, a, m, st);
+    int rc = launch_mlp(h, a, m, st, /*decode=*/true);
     if (rc) return rc;
     cur ^= 1;
   }

@@ -196,7 +196,8 @@ def test_device_tensor_path_and_model_api(engines):
     xn = (x - sd["data_mean"]) / sd["data_std"]
     c2, xhat = model.encode(xn)
     assert np.array_equal(c2, codes_np)
-    assert np.allclose(model.decode(c2), xhat, rtol=0, atol=0)
+    # (encode tracks its reconstruction with the folded kernel, decode runs the un-folded instance: same value to rounding)
+    assert rel_err(model.decode(c2), xhat) < 1e-6
     assert np.array_equal(model.decode(c2) * sd["data_std"] + sd["data_mean"], model(c2, step="decode"))
 
 

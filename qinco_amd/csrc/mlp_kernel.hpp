@@ -478,15 +478,23 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   stamp(5);   // stores / tail DMAs retired
 }
 
-// U[g] = W_cat[:, De:] . xhat_g for every (vector, beam) group (FOLD).  Same transposed-MFMA form: a wave keeps its 32
-// groups' xhat as B operands and streams the (De x D) weight fragments (L2 resident) as A operands.
+// U[g] = W_cat[:, De:] . xhat_g for every (vector, beam) group (FOLD), and Q[g] = W_up[0] . U[g] (FOLD2).  Same transposed-MFMA
+// form: a wave keeps its 32 groups' xhat as B operands and consumes the weight fragments (wx: De x D, then wq: Dh x De, in
+// (ob, ib, q) order) as A operands; U's C layout is Q's B layout, so Q chains on the U blocks still in registers.
+// Round 2: the fragments come through LDS, shared by the 4 waves of the workgroup -- chunks of 16 fragments (16 KiB),
+// double-buffered, each wave LDS-DMAs a quarter of the next chunk while the current one is consumed, one barrier per chunk.
+// Round 1 let every wave load every fragment straight from L2 with no look-ahead: latency-bound at 35-45 % of the fp32-MFMA
+// peak, and 4096 waves x 192 KiB of L2 -> L1 traffic per call at the qinco2-S shape.  Same MFMA order, same results.
 template <int D, int DE, int DH>
 __global__ void __launch_bounds__(256) xproj_kernel(XprojArgs a) {
-  constexpr int NDB = D / 32, NEB = DE / 32;
+  constexpr int NDB = D / 32, NEB = DE / 32, NHB = DH / 32;
+  constexpr int CH = 16;                              // fragments per chunk
+  constexpr int NFU = NEB * NDB * 4, NFQ = NHB * NEB * 4;
+  __shared__ f32x4 lds_w[2 * CH * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int j = lane & 31, half = lane >> 5;
-  const long g0 = ((long)blockIdx.x * 4 + wave) * 32;
-  if (g0 >= a.G) return;
+  const long g0 = ((long)blockIdx.x * 4 + wave) * 32;   // every wave runs (barriers); groups past G are clamped, never stored
   long g = g0 + j;
   const bool valid = g < a.G;
   if (!valid) g = a.G - 1;
@@ -494,52 +502,72 @@ __global__ void __launch_bounds__(256) xproj_kernel(XprojArgs a) {
   f32x16 xt[NDB];
 #pragma unroll
   for (int ib = 0; ib < NDB; ++ib) xt[ib] = load_block(xp + ib * 32);
-  const f32x4* wp = a.wx + lane;
+
+  // chunk c of a stream -> buffer c & 1; wave w fetches fragments w, w + 4, ... of the chunk
+  auto dma_chunk = [&]<int C, int NF>(const f32x4* stream) QINCO_LAMBDA {
+    constexpr int n = (NF - C * CH) < CH ? (NF - C * CH) : CH;
+    static_for<(n + 3) / 4>([&]<int i>() QINCO_LAMBDA {
+      const int f = wave_u + 4 * i;
+      if (f < n)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(stream + (C * CH + f) * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(lds_w + ((C & 1) * CH + f) * 64), 16, 0, 0);
+    });
+  };
+  // boundary before chunk C of a stream whose output blocks take FPO fragments each: this wave's DMAs of chunk C have
+  // landed -- they are older than the block stores issued while chunk C-1 was consumed (4 per finished block, issued by every
+  // lane, so the count is exact and vmcnt retires in order) --, every wave is done with the other buffer, chunk C+1 is requested
+  auto boundary = [&]<int C, int NF, int FPO>(const f32x4* stream) QINCO_LAMBDA {
+    constexpr int lo = C > 0 ? (C - 1) * CH : 0, hi = C * CH;
+    constexpr int nstores = C > 0 ? 4 * ((hi / FPO) - (lo / FPO)) : 0;   // blocks finished inside [lo, hi)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (nstores & 15) | ((nstores >> 4) << 14));
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr ((C + 1) * CH < NF) dma_chunk.template operator()<C + 1, NF>(stream);
+  };
+  auto frag = [&]<int F>() QINCO_LAMBDA -> f32x4 { return lds_w[(((F / CH) & 1) * CH + F % CH) * 64 + lane]; };
+  // (lanes past G hold copies of group G-1: they store the same values to the same place)
+  auto store_block = [&](float* p, const f32x16& v) QINCO_LAMBDA {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      *reinterpret_cast<f32x4*>(p + 8 * q) = t;
+    }
+  };
+
   float* up = a.uproj + g * DE + half * 4;
   f32x16 u[NEB];
-#pragma unroll
-  for (int ob = 0; ob < NEB; ++ob) {
+  dma_chunk.template operator()<0, NFU>(a.wx);
+  static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
     f32x16 acc = zero16();
-#pragma unroll
-    for (int ib = 0; ib < NDB; ++ib)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 w = wp[((ob * NDB + ib) * 4 + q) * 64];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = QINCO_MFMA(w[e], xt[ib][4 * q + e], acc);
-      }
+    static_for<NDB * 4>([&]<int t>() QINCO_LAMBDA {
+      constexpr int F = ob * NDB * 4 + t;
+      if constexpr (F % CH == 0) boundary.template operator()<F / CH, NFU, NDB * 4>(a.wx);
+      const f32x4 w = frag.template operator()<F>();
+      static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA(w[e], xt[t / 4][4 * (t % 4) + e], acc); });
+    });
     u[ob] = acc;
-    if (valid) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 t = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        *reinterpret_cast<f32x4*>(up + ob * 32 + 8 * q) = t;
-      }
-    }
-  }
-  if (a.wq) {   // FOLD2: Q = W_up[0] . U, chained on the U blocks still in registers (C layout = B layout)
-    const f32x4* wq = a.wq + lane;
+    store_block(up + ob * 32, u[ob]);
+  });
+  if (a.wq) {   // FOLD2 (wave-uniform): Q = W_up[0] . U
     float* qp = a.qproj + g * DH + half * 4;
-#pragma unroll
-    for (int ob = 0; ob < DH / 32; ++ob) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // every wave has left the U stream's buffers
+    dma_chunk.template operator()<0, NFQ>(a.wq);
+    static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
       f32x16 acc = zero16();
-#pragma unroll
-      for (int ib = 0; ib < NEB; ++ib)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 w = wq[((ob * NEB + ib) * 4 + q) * 64];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = QINCO_MFMA(w[e], u[ib][4 * q + e], acc);
-        }
-      if (valid) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 t = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-          *reinterpret_cast<f32x4*>(qp + ob * 32 + 8 * q) = t;
-        }
-      }
-    }
+      static_for<NEB * 4>([&]<int t>() QINCO_LAMBDA {
+        constexpr int F = ob * NEB * 4 + t;
+        if constexpr (F % CH == 0) boundary.template operator()<F / CH, NFQ, NEB * 4>(a.wq);
+        const f32x4 w = frag.template operator()<F>();
+        static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA(w[e], u[t / 4][4 * (t % 4) + e], acc); });
+      });
+      store_block(qp + ob * 32, acc);
+    });
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the wave ends
 }
 
 }  // namespace qinco

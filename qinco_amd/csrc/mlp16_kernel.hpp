@@ -24,6 +24,14 @@
 namespace qinco {
 
 #define QINCO_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// Bisection switches for the co-residency failure of this kernel (experiment builds only, scripts/build_exp_lib.py):
+//   1 ring registers pinned to VGPRs (hipcc lets the LDS reads land in AGPRs)      2 full s_waitcnt 0 behind every barrier
+//   4 __syncthreads() instead of the raw s_barrier                                 8 no read-ahead: fragment T is read at take<T>
+//  16 epilogue without the x loads (distances of garbage)                         64 lgkmcnt(0) joins the counted vmcnt in front of every barrier
+// 128 lgkmcnt(0) once, behind the bias fragments' reads
+#ifndef QINCO_EXP16
+#define QINCO_EXP16 0
+#endif
 
 template <int D, int DE, int DH, int P>
 __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
@@ -60,7 +68,8 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
   };
   auto wait_vm = [&]<int N>() QINCO_LAMBDA {
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+    if constexpr (QINCO_EXP16 & 64) __builtin_amdgcn_s_waitcnt(0x0070 | (N & 15) | ((N >> 4) << 14));   // + lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
     asm volatile("" ::: "memory");
   };
   static_for<P / 4 - 1>([&]<int i>() QINCO_LAMBDA { dma.template operator()<4 * i>(); });
@@ -71,10 +80,22 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
   auto take = [&]<int T>() QINCO_LAMBDA -> f32x4 {
     if constexpr ((T & 3) == 0) {
       wait_vm.template operator()<P / 4 - 3>();
-      __builtin_amdgcn_s_barrier();
+      if constexpr (QINCO_EXP16 & 4) __syncthreads();
+      else __builtin_amdgcn_s_barrier();
+      if constexpr (QINCO_EXP16 & 2) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0);
+        asm volatile("" ::: "memory");
+      }
       dma.template operator()<T + P - 4>();
     }
+    if constexpr (QINCO_EXP16 & 8) {
+      f32x4 w = myring[(T % P) * 64 + lane];
+      if constexpr (QINCO_EXP16 & 1) asm volatile("" : "+v"(w));
+      return w;
+    }
     ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
+    if constexpr (QINCO_EXP16 & 1) asm volatile("" : "+v"(ring[(T + 2) % 3]));
     return ring[T % 3];
   };
   auto skip_pad = [&]<int FROM, int TO>() QINCO_LAMBDA {
@@ -82,7 +103,14 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
   };
   // acc (16 output features x 16 rows) += W[ob, ib] . b   -- 4 MFMAs, one per register of the input block
   auto fragmm = [&]<int T>(f32x4& acc, const f32x4& b) QINCO_LAMBDA {
-    const f32x4 w = take.template operator()<T>();
+    f32x4 w = take.template operator()<T>();
+    // The ring recycles the slots of fragments <= T - 1 at the next barrier, so this wave's LDS read of every such fragment
+    // must have COMPLETED before it arrives there.  Program order alone does not give that: hipcc moves the MFMAs -- and with
+    // them the s_waitcnt lgkmcnt that completes the ds_read -- across s_barrier, and with three workgroups per CU (LDS pipe
+    // ~75 % busy with this kernel's 1 KiB per wave per 128 cycles) the refill from L2 can land before a queued read executes:
+    // about one wave in a hundred computed with a refilled (wrong) fragment.  The pin makes the fragment a register value at
+    // this point of the program; asm volatile does not cross the barrier's fences.  (round-2 bisection)
+    pin4_v(w);
     static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA16(w[e], b[e], acc); });
   };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -106,7 +134,15 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
   }
 
   // ---- B: y = bias of the concat Linear ---------------------------------------------------------------------
-  static_for<NEB>([&]<int ob>() QINCO_LAMBDA { y[ob] = take.template operator()<ob>(); });
+  static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+    y[ob] = take.template operator()<ob>();
+    pin4_v(y[ob]);   // (see fragmm: the bias fragments land straight in y and would stay in flight for a whole section)
+  });
+  if constexpr (QINCO_EXP16 & 128) {   // the bias fragments have left LDS before this wave goes on to the barriers that recycle their slots
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    asm volatile("" ::: "memory");
+  }
   skip_pad.template operator()<NEB, SL.T_BIAS>();
   wp += SL.T_BIAS * 64;
 
@@ -167,7 +203,7 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
     o = o + load_blk(xhptr + ob * 16);
     if (valid) *reinterpret_cast<f32x4*>(outp + ob * 16) = o;
     if (xptr) {
-      const f32x4 xb = load_blk(xptr + ob * 16);
+      const f32x4 xb = (QINCO_EXP16 & 16) ? zero4 : load_blk(xptr + ob * 16);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         s2 = fmaf(o[i], o[i], s2);

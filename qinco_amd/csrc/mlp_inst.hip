@@ -8,23 +8,18 @@
 #define QINCO_CAT_(a, b, c, d, e, f) a##b##_##c##_##d##_##e##_##f
 #define QINCO_CAT(a, b, c, d, e, f) QINCO_CAT_(a, b, c, d, e, f)
 
-// Co-residency of the shared-ring kernels.  With small models the 16-row kernel (mlp16_kernel.hpp) fits 3 workgroups per CU, and
-// then single waves produce wrong rows now and then (about 1 wave in 100 at 1500 workgroups; exact and deterministic with
-// one workgroup per CU).  Round-2 findings (scripts/ubench/ring_check.hip, scripts/exp_coresidency.py): the ring
-// itself delivers the right bytes at 1-3 workgroups per CU, VGPR loads issued among the LDS-DMAs retire in order, and the
-// 32-row kernels are exact at 2-3 workgroups per CU -- so only the 16-row kernel keeps the padding (its one production
-// shape, De = D = 768, is exclusive by registers anyway).
+// Co-residency of the shared-ring kernels.  Round 1 padded every shared-ring launch with dummy dynamic LDS so that two
+// workgroups could not share a CU: with small models the 16-row kernel fits 3 per CU and then ~1 wave in 100 computed with a
+// wrong weight fragment.  Round 2 found the cause (mlp16_kernel.hpp, fragmm): hipcc moves the consuming MFMAs
+// and the lgkmcnt wait of a fragment's LDS read below the s_barrier that licenses the refill of its ring slot.  With the
+// fragments pinned where they are consumed the kernels are exact at 1-3 workgroups per CU and nothing is padded any more.
+// QINCO_RING_PAD_KIB=n (experiments) still pads every shared-ring launch.
 static unsigned exclusive_lds() {
-  // 16-row kernel: 48 KiB static + 36 = 84 > 80 -> one workgroup per CU.  The 32-row ring kernels share a CU freely (ring
-  // checker, scripts/exp_coresidency.py and the bitwise variant tests at 2-3 workgroups per CU are clean).
-  // QINCO_RING_PAD_KIB (experiments) overrides the padding of every shared-ring kernel.
   static const int env = [] {
     const char* e = getenv("QINCO_RING_PAD_KIB");
     return e ? atoi(e) : -1;
   }();
-  if (!(QVAR & 64)) return 0u;
-  if (env >= 0) return (unsigned)env * 1024u;
-  return (QVAR & 128) ? 36u * 1024u : 0u;
+  return ((QVAR & 64) && env >= 0) ? (unsigned)env * 1024u : 0u;
 }
 #define kExclusiveLds exclusive_lds()
 

@@ -95,6 +95,7 @@ QINCO_INL void relu16(f32x16& v) {
 // Register-class pins: empty asm statements that force a 16-register block into VGPRs / AGPRs at that point
 // (clang cannot reference lambda captures from an asm operand, hence the helpers).
 QINCO_INL void pin_v(f32x16& v) { asm volatile("" : "+v"(v)); }
+QINCO_INL void pin4_v(f32x4& v) { asm volatile("" : "+v"(v)); }
 QINCO_INL void pin_a(f32x16& v) { asm volatile("" : "+a"(v)); }
 
 template <int D, int DE, int DH, int P, int VAR>
@@ -200,6 +201,7 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
         dma.template operator()<T + P - 4>();
       }
       ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
+      asm volatile("" ::: "memory");   // the ring reads keep their program order (see fragmm)
       return ring[T % 3];
     } else if constexpr (LDSR) {
       // fragments T, T+1 are in ring[]; fragment T+2's DMA is P-4 DMAs old; refill the slot of fragment T-1.
@@ -220,7 +222,15 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   // (a slice of a chain epilogue that the following MFMAs do not depend on).
   auto noop = []() QINCO_LAMBDA {};
   auto fragmm = [&]<int T, int q>(f32x16& acc, const f32x16& b, auto&& extra) QINCO_LAMBDA {
-    const f32x4 w = take.template operator()<T>();
+    f32x4 w = take.template operator()<T>();
+    // Shared ring: the barrier in front of fragment T + 1 (T = 3 mod 4) licenses the refill of the slots of fragments <= T, so
+    // this wave's LDS reads of those fragments must have COMPLETED when it arrives there.  Program order alone does not give
+    // that -- hipcc moves MFMAs, and with them the s_waitcnt lgkmcnt that completes a ds_read, across s_barrier (found on the
+    // 16-row kernel, where it corrupted ~1 wave in 100 at three workgroups per CU: mlp16_kernel.hpp).  The
+    // pin makes the last fragment ahead of the barrier a register value at this point of the program; the ring reads are
+    // issued in program order (memory fences in take) and LDS returns a wave's reads in order, so every earlier fragment has
+    // arrived too; asm volatile does not cross the barrier's fences.  Costs 0.8 % at C2, gains 1.2 % at qinco2-S.
+    if constexpr (SHR && (T & 3) == 3) pin4_v(w);
     static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA(w[e], b[4 * q + e], acc); });
     extra();
   };
@@ -270,6 +280,7 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
       static_for<4>([&]<int q>() QINCO_LAMBDA {
         f32x4 w = take.template operator()<ob * 4 + q>();
+        if constexpr (SHR && ((ob * 4 + q) & 3) == 3) pin4_v(w);   // (see fragmm)
         static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob][4 * q + e] = w[e]; });
       });
     });
@@ -525,7 +536,14 @@ __global__ void __launch_bounds__(256) xproj_kernel(XprojArgs a) {
     __builtin_amdgcn_s_barrier();
     if constexpr ((C + 1) * CH < NF) dma_chunk.template operator()<C + 1, NF>(stream);
   };
-  auto frag = [&]<int F>() QINCO_LAMBDA -> f32x4 { return lds_w[(((F / CH) & 1) * CH + F % CH) * 64 + lane]; };
+  // (the last fragment of a chunk is pinned: its LDS read -- and, reads being issued and returned in order, every earlier one --
+  // has completed before this wave reaches the boundary that lets the other waves refill the buffer; see mlp_kernel fragmm)
+  auto frag = [&]<int F>() QINCO_LAMBDA -> f32x4 {
+    f32x4 w = lds_w[(((F / CH) & 1) * CH + F % CH) * 64 + lane];
+    asm volatile("" ::: "memory");
+    if constexpr (F % CH == CH - 1) pin4_v(w);
+    return w;
+  };
   // (lanes past G hold copies of group G-1: they store the same values to the same place)
   auto store_block = [&](float* p, const f32x16& v) QINCO_LAMBDA {
 #pragma unroll

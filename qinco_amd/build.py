@@ -65,7 +65,10 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     o = OBJ / "qinco_hip.o"
     objs.append(o)
     if force or not _newer(o, headers + [CSRC / "qinco_hip.hip"]):
-        tasks.append((o, [cc, *FLAGS, "-c", str(CSRC / "qinco_hip.hip"), "-o", str(o)]))
+        # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs.  The table / filter kernels post-process every accumulator on the VALU
+        # (arg-min, max, compare), which cannot read AGPRs: with AGPR accumulators the IVF filter spent 3 of 4 VALU instructions
+        # on v_accvgpr_read / write (csrc/ivf_f16_kernel.hpp).  The fused-MLP instances are separate objects and keep their plan.
+        tasks.append((o, [cc, *FLAGS, "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", str(CSRC / "qinco_hip.hip"), "-o", str(o)]))
     o = OBJ / "search_hip.o"
     objs.append(o)
     if force or not _newer(o, [CSRC / n for n in ("search_hip.hip", "knn_kernel.hpp", "abi_util.hpp", "mlp_args.hpp")]

@@ -38,7 +38,7 @@ __device__ __forceinline__ float f32_from_ordered(unsigned u) {
 
 struct IvfF16Args {
   const h16x8* cstream;     // fp16 centroid fragments: (block of 32, k-step of 16 features) -> 64 lanes x 8 halfs
-  const float* cnorm_half;  // |c_k|^2 / 2 (fp32, of the fp32 centroids)
+  const float* cnorm_half;  // -|c_k|^2 / 2 (fp32, of the fp32 centroids): the accumulators' start value, loaded as is
   int nblocks, blocks_per_slice;
   const float* x;           // (N, D) normalised vectors, fp32
   long N;
@@ -56,8 +56,14 @@ template <int D, int MODE>
 __global__ void __launch_bounds__(256)
 ivf_f16_kernel(IvfF16Args a) {
   constexpr int NK = D / 16;                 // k-steps (fragments) per block of 32 centroids
-  constexpr int VS = D <= 256 ? 2 : 1;       // sets of 32 vectors per wave (4 sets: pass A -12 %, pass B +34 %)
-  constexpr int P = NK >= 8 ? 8 : NK;        // ring depth in fragments (divides NK for every supported D)
+#ifndef QINCO_IVF_VS
+#define QINCO_IVF_VS(D) ((D) <= 128 ? 4 : ((D) <= 256 ? 2 : 1))
+#endif
+  // sets of 32 vectors per wave.  A 1 KiB fragment feeds VS MFMAs of 32 cycles: with 2 sets and 2 waves per SIMD the eight
+  // waves of a CU ask the L1 for 128 B/clk, twice what it delivers; 4 sets (one wave per SIMD: 293 registers) ask for 32.
+  // Round 2, ivf_K = 2^20, 16 384 vectors: pass A 4.37 -> 4.00 (VGPR accumulators) -> 3.25 ms (4 sets), pass B 4.35 -> 3.56 ms.
+  constexpr int VS = QINCO_IVF_VS(D);
+  constexpr int P = NK >= 8 ? 8 : NK;        // ring depth in fragments (divides NK for every supported D; 16 was slower)
   static_assert(NK % P == 0, "ring depth must divide the fragments per block");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
@@ -112,29 +118,31 @@ ivf_f16_kernel(IvfF16Args a) {
 #pragma unroll
   for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
 
-  // The accumulators start at -|c|^2/2, so the tile comes out as  -s~ = x~.c~ - |c|^2/2  and the epilogue is ONE VALU
-  // instruction per (vector, centroid) pair (v_max in pass A, v_cmp in pass B) instead of subtract + min.  The
-  // centroid norms of the next block are fetched during the current one.
-  f32x4 cn[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) cn[g] = *reinterpret_cast<const f32x4*>(a.cnorm_half + cb0 * 32 + 8 * g + 4 * half);
+  // The accumulators start at -|c|^2/2, so the tile comes out as  -s~ = x~.c~ - |c|^2/2.  Round 2: the negated half norms
+  // are LOADED straight into the accumulators -- two sets of them, the next block's start values arrive while the current
+  // block is on the matrix pipe -- and the accumulators are pinned to VGPRs.  Round 1 kept them in AGPRs, where the VALU cannot
+  // read: per tile of 8 MFMAs it spent 16 v_xor (negation) + 16 v_accvgpr_write + 32 v_accvgpr_read next to the 16 v_max3 that
+  // do the work, all serial with the MFMAs inside the wave (40 % of the fp16 peak).
   float nthr[VS];
 #pragma unroll
   for (int s = 0; s < VS; ++s) {
     nthr[s] = -thr[s];
     mn[s] = -__builtin_inff();  // running maximum of -s~
   }
-  auto block = [&](const int cb) __attribute__((always_inline)) {
-    f32x16 acc[VS];
+  f32x16 acc[2][VS];
+  auto load_start = [&](const int cb, f32x16 (&dst)[VS]) __attribute__((always_inline)) {
+    const int cbc = cb < a.nblocks ? cb : a.nblocks - 1;
 #pragma unroll
     for (int s = 0; s < VS; ++s)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(a.cnorm_half + cbc * 32 + 8 * g + 4 * half);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[s][4 * g + e] = -cn[g][e];
-    const int cbn = cb + 1 < a.nblocks ? cb + 1 : cb;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) cn[g] = *reinterpret_cast<const f32x4*>(a.cnorm_half + cbn * 32 + 8 * g + 4 * half);
+        for (int e = 0; e < 4; ++e) dst[s][4 * g + e] = t[e];
+      }
+  };
+  auto block = [&](const int cb, f32x16 (&cur)[VS], f32x16 (&nxt)[VS]) __attribute__((always_inline)) {
+    load_start(cb + 1, nxt);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
       const h16x8 w = ring[k % P];
@@ -142,7 +150,7 @@ ivf_f16_kernel(IvfF16Args a) {
       asm volatile("" ::: "memory");  // keep the ring loads where they are (see ivf_assign_kernel)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < VS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, xt[s][k], acc[s], 0, 0, 0);
+      for (int s = 0; s < VS; ++s) cur[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, xt[s][k], cur[s], 0, 0, 0);
     }
     wp += NK * 64;
     // lane holds centroids cb*32 + 8g + 4*half + e (register 4g + e) of vector j of each set
@@ -150,13 +158,16 @@ ivf_f16_kernel(IvfF16Args a) {
 #pragma unroll
       for (int s = 0; s < VS; ++s)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mn[s] = fmaxf(mn[s], acc[s][i]);
+        for (int i = 0; i < 16; ++i) mn[s] = fmaxf(mn[s], cur[s][i]);
     } else {
       bool any = false;
 #pragma unroll
-      for (int s = 0; s < VS; ++s)
+      for (int s = 0; s < VS; ++s) {
+        float m = cur[s][0];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) any |= acc[s][i] >= nthr[s];
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, cur[s][i]);   // v_max3: 8 instructions, then ONE compare per set
+        any |= m >= nthr[s];
+      }
       if (__builtin_expect(__any(any), 0)) {  // rare: about one hit per vector in ivf_K centroids
 #pragma unroll
         for (int s = 0; s < VS; ++s)
@@ -164,7 +175,7 @@ ivf_f16_kernel(IvfF16Args a) {
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (valid[s] && acc[s][4 * g + e] >= nthr[s]) {
+              if (valid[s] && cur[s][4 * g + e] >= nthr[s]) {
                 const int pos = atomicAdd(a.cand_count, 1);
                 if (pos < a.cand_cap) {
                   a.cand_vec[pos] = (int)vec[s];
@@ -177,13 +188,14 @@ ivf_f16_kernel(IvfF16Args a) {
     }
   };
   int cb = cb0;
-  if constexpr (NK <= 8) {  // two blocks per trip: exact waitcnts inside straight-line code (see ivf_assign_kernel)
-    for (; cb + 1 < cb1; cb += 2) {
-      block(cb);
-      block(cb + 1);
-    }
+  load_start(cb0, acc[0]);
+  // two blocks per trip: the accumulator sets alternate with compile-time indices, and the waitcnts inside straight-line code
+  // are counted exactly (see ivf_assign_kernel)
+  for (; cb + 1 < cb1; cb += 2) {
+    block(cb, acc[0], acc[1]);
+    block(cb + 1, acc[1], acc[0]);
   }
-  for (; cb < cb1; ++cb) block(cb);
+  if (cb < cb1) block(cb, acc[0], acc[1]);
 
   if constexpr (MODE == 0) {
 #pragma unroll

@@ -102,7 +102,7 @@ struct qinco_handle_s {
   bool table_valu = false;          // QINCO_TABLE_VALU=1 at create: VALU pre-selection table kernel (A/B)
   bool ivf_f16 = false;
   void* ivf_h16 = nullptr;           // centroids as fp16 MFMA fragments
-  float* ivf_cnorm_half = nullptr;   // |c|^2 / 2
+  float* ivf_cnorm_half = nullptr;   // -|c|^2 / 2
   float ivf_cmax = 0.f;
   unsigned* ivf_amin = nullptr;      // (max_batch) approximate minima
   int* ivf_cand = nullptr;           // [count, overflow, pad, pad][vec (cap)][id (cap)]
@@ -287,7 +287,7 @@ static int build_ivf_f16(qinco_handle_s* h, const float* cb) {
       s2 += (double)v * v;
       amax = fmaxf(amax, fabsf(v));
     }
-    nh[k] = 0.5f * s;  // same |c|^2 as upload_with_norms, halved exactly
+    nh[k] = -0.5f * s;  // same |c|^2 as upload_with_norms, halved exactly and negated: the filter accumulators' start value
     if (s2 > n2max) n2max = s2;
   }
   if (!(amax < 60000.f)) return 0;  // outside the fp16 range: the exact fp32 kernel is used on its own
@@ -804,7 +804,7 @@ static int launch_ivf_assign(qinco_handle_s* h, long n, hipStream_t st) {
     a.cand_cap = h->ivf_cand_cap;
     a.cand_vec = h->ivf_cand + 4;
     a.cand_id = h->ivf_cand + 4 + h->ivf_cand_cap;
-    const int vs = d.D <= 256 ? 2 : 1;
+    const int vs = QINCO_IVF_VS(d.D);
     const long tiles = (n + 128 * vs - 1) / (128 * vs);
     long slices;
     ivf_grid(tiles, nblocks, 2048, &a.blocks_per_slice, &slices);

@@ -25,7 +25,7 @@ for (d, de, dh, p, var) in shapes:
                                    str(B.CSRC / "mlp_inst.hip"), "-o", str(o)]))
     objs[o.name] = o
 o = obj_dir / "qinco_hip.o"
-procs.append(subprocess.Popen([cc, *B.FLAGS, *defs, "-c", str(B.CSRC / "qinco_hip.hip"), "-o", str(o)]))
+procs.append(subprocess.Popen([cc, *B.FLAGS, *defs, "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", str(B.CSRC / "qinco_hip.hip"), "-o", str(o)]))
 objs[o.name] = o
 for p in procs:
     assert p.wait() == 0

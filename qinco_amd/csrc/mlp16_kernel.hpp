@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
       return w;
     }
     ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
+    asm volatile("" ::: "memory");   // the ring reads keep their program order (see fragmm)
     if constexpr (QINCO_EXP16 & 1) asm volatile("" : "+v"(ring[(T + 2) % 3]));
     return ring[T % 3];
   };
@@ -110,8 +111,20 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
     // ~75 % busy with this kernel's 1 KiB per wave per 128 cycles) the refill from L2 can land before a queued read executes:
     // about one wave in a hundred computed with a refilled (wrong) fragment.  The pin makes the fragment a register value at
     // this point of the program; asm volatile does not cross the barrier's fences.  (round-2 bisection)
+#if QINCO_EXP16 & 512   // experiment: pin every fragment (the first form of the fix: -3.6 % on the production shape)
     pin4_v(w);
+#else
+    // Lighter form, as in mlp_kernel: the ring reads keep their program order (memory fence in take), LDS returns a wave's reads
+    // in order, so pinning the LAST fragment in front of each barrier covers the earlier ones; a section whose live fragments do
+    // not end on such a fragment finishes with lgkmcnt(0) (section_done).
+    if constexpr ((T & 3) == 3) pin4_v(w);
+#endif
     static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA16(w[e], b[e], acc); });
+  };
+  auto section_done = [&]() QINCO_LAMBDA {   // every LDS read of this wave has completed (once per section)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    asm volatile("" ::: "memory");
   };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -127,6 +140,7 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
       if constexpr (ib + 1 < NDB) cb = load_blk(cptr + (ib + 1) * 16);
       static_for<NEB>([&]<int ob>() QINCO_LAMBDA { fragmm.template operator()<ib * NEB + ob>(z[ob], cur); });
     });
+    section_done();
     skip_pad.template operator()<NEB * NDB, SL.T_IN>();
     wp += SL.T_IN * 64;
   } else {
@@ -159,6 +173,7 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
       }
       static_for<NEB>([&]<int ob>() QINCO_LAMBDA { fragmm.template operator()<ib * NEB + ob>(y[ob], b); });
     });
+    section_done();
     skip_pad.template operator()<NEB*(NEB + NDB), SL.T_CAT>();
     wp += SL.T_CAT * 64;
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = z[ob] + y[ob]; });
@@ -174,12 +189,14 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
     static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
       static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob][e] = relu1(y[ob][e]); });
     });
+    section_done();
     skip_pad.template operator()<NEB * NHB, SL.T_UP>();
     wp += SL.T_UP * 64;
     // the down-projection accumulates straight into z: the residual add is the MFMA's C operand
     static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
       static_for<NEB>([&]<int ob>() QINCO_LAMBDA { fragmm.template operator()<ib * NEB + ob>(z[ob], y[ib]); });
     });
+    section_done();
     skip_pad.template operator()<NHB * NEB, SL.T_DOWN>();
     wp += SL.T_DOWN * 64;
   }

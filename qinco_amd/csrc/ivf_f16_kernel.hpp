@@ -63,7 +63,7 @@ ivf_f16_kernel(IvfF16Args a) {
   // waves of a CU ask the L1 for 128 B/clk, twice what it delivers; 4 sets (one wave per SIMD: 293 registers) ask for 32.
   // Round 2, ivf_K = 2^20, 16 384 vectors: pass A 4.37 -> 4.00 (VGPR accumulators) -> 3.25 ms (4 sets), pass B 4.35 -> 3.56 ms.
   constexpr int VS = QINCO_IVF_VS(D);
-  constexpr int P = NK >= 8 ? 8 : NK;        // ring depth in fragments (divides NK for every supported D; 16 was slower)
+  constexpr int P = NK >= 8 ? 8 : NK;        // ring depth in fragments (divides NK for every supported D; 16 was slower, twice)
   static_assert(NK % P == 0, "ring depth must divide the fragments per block");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;

@@ -291,7 +291,7 @@ static int build_ivf_f16(qinco_handle_s* h, const float* cb) {
     if (s2 > n2max) n2max = s2;
   }
   if (!(amax < 60000.f)) return 0;  // outside the fp16 range: the exact fp32 kernel is used on its own
-  std::vector<_Float16> s((size_t)K * D + (size_t)8 * 512);
+  std::vector<_Float16> s((size_t)K * D + (size_t)32 * 512);   // the filter kernels' ring prefetches up to 16 fragments past the end
   size_t o = 0;
   for (int b = 0; b < K / 32; ++b)
     for (int k = 0; k < NK; ++k)

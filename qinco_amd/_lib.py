@@ -11,10 +11,11 @@ LIB_PATH = PKG / "libqinco_hip.so"
 X_F32, X_U8 = 0, 1
 CODE_I64, CODE_I32, CODE_U8 = 0, 1, 2
 FLAG_NORMALISED = 1
+CREATE_SPLIT_F16 = 1
 
 # every symbol include/qinco_hip.h declares (tests check the library exports all of them)
 API_SYMBOLS = [
-    "qinco_create", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
+    "qinco_create", "qinco_create_ex", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
     "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
     "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
@@ -85,6 +86,7 @@ def load() -> C.CDLL:
         raise QincoLibraryError(f"cannot load {path}: {e}") from e
     vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
     lib.qinco_create.argtypes = [C.POINTER(QincoDesc), C.POINTER(QincoWeights), C.POINTER(vp)]
+    lib.qinco_create_ex.argtypes = [C.POINTER(QincoDesc), C.POINTER(QincoWeights), C.c_int32, C.POINTER(vp)]
     lib.qinco_destroy.argtypes = [vp]
     lib.qinco_set_beam.argtypes = [vp, C.c_int32, C.c_int32]
     lib.qinco_encode.argtypes = [vp, vp, i32, i64, i64, vp, i32, vp, i32, vp]

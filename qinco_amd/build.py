@@ -52,7 +52,7 @@ def _run(cmd: list[str]) -> None:
 def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> Path:
     OBJ.mkdir(exist_ok=True)
     cc = hipcc()
-    mlp_deps = [CSRC / n for n in ("mlp_kernel.hpp", "mlp16_kernel.hpp", "mlp_args.hpp", "mlp_launch.hpp", "mlp_inst.hip")]
+    mlp_deps = [CSRC / n for n in ("mlp_kernel.hpp", "mlp16_kernel.hpp", "mlp_split_kernel.hpp", "mlp_args.hpp", "mlp_launch.hpp", "mlp_inst.hip")]
     headers = sorted(CSRC.glob("*.hpp")) + [CSRC / "shapes.def", PKG.parent / "include" / "qinco_hip.h"]
     tasks: list[tuple[Path, list[str]]] = []
     objs: list[Path] = []

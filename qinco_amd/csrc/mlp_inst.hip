@@ -3,6 +3,7 @@
 
 #include "mlp_kernel.hpp"
 #include "mlp16_kernel.hpp"
+#include "mlp_split_kernel.hpp"
 #include "mlp_launch.hpp"
 
 #define QINCO_CAT_(a, b, c, d, e, f) a##b##_##c##_##d##_##e##_##f
@@ -26,7 +27,11 @@ static unsigned exclusive_lds() {
 extern "C" __attribute__((visibility("hidden")))
 hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::MlpArgs* a, hipStream_t stream) {
   if (a->R <= 0) return hipSuccess;
-#if (QVAR & 128)  // 16-row tile form (mlp16_kernel.hpp)
+#if (QVAR & 512)  // split-fp16 FFN blocks (mlp_split_kernel.hpp)
+  const long tiles = (a->R + 31) / 32;
+  const unsigned grid = (unsigned)((tiles + 3) / 4);
+  hipLaunchKernelGGL((qinco::mlp_split_kernel<QD, QDE, QDH, QP>), dim3(grid), dim3(256), 0, stream, *a);
+#elif (QVAR & 128)  // 16-row tile form (mlp16_kernel.hpp)
   const long tiles = (a->R + 15) / 16;
   const unsigned grid = (unsigned)((tiles + 3) / 4);
   hipLaunchKernelGGL((qinco::mlp16_kernel<QD, QDE, QDH, QP>), dim3(grid), dim3(256), kExclusiveLds, stream, *a);

@@ -1,0 +1,289 @@
+// Split-fp16 form of the fused codeword-MLP kernel (VAR bit 512; opt-in: qinco_create_ex flag QINCO_FLAG_SPLIT_F16).
+//
+// Same function, tile (a wave owns 32 rows and all features), folded head (z = T[cid] + U[group], y = relu(P[cid] + Q[group]))
+// and fp32 tail (out_proj, candidate, distance) as mlp_kernel.hpp -- only the L residual FFN blocks, 94 % of the FLOPs at the
+// qinco2-L shape, are evaluated differently: fp32-in MFMA runs at the f32 vector rate on gfx950 (1/16 of the fp16 rate), so
+// each fp32 operand is split into two fp16 values, v = hi + lo with hi = fp16(v), lo = fp16(v - hi) (22 significand bits), and
+//     W.x  ~=  Whi.xhi + Whi.xlo + Wlo.xhi            (the dropped Wlo.xlo term is 2^-22 relative)
+// on v_mfma_f32_32x32x16_f16 with fp32 accumulation: three MFMAs of 32 cycles for the K = 16 that costs eight fp32 MFMAs of
+// 64 cycles.  Every product of two fp16 values is exact in fp32, the accumulation is fp32 as before; measured against
+// float64 the result is in the same error class as the fp32 MFMA chain (scripts/ubench/split16.hip: 2.5e-7 vs 2.3e-7 rms at
+// K = 384).  fp16 has 5 exponent bits: a lo part below 2^-14 is subnormal and loses bits, so the operands are kept at
+// magnitudes where that does not matter by exact power-of-two scalings chosen on the host (qinco_hip.hip, split_scales):
+//     z is held as z' = 2^c z, h as h' = 2^a h, W_up' = 2^d W_up, W_down' = 2^b W_down (d, b per layer) and the chain
+//     accumulators are scaled back by one fp32 multiply in the epilogue they need anyway (smul[] below).
+//
+// Register plan (one wave per SIMD, up to 512 registers):
+//   z'  fp32 master (VALU-updated by the residual add; split on the fly as the up-projection's B operand): NEB x 16 registers.
+//       z' + y + the weight quads need 478 registers at De = Dh = 384 and hipcc cannot balance that over the VGPR / AGPR
+//       halves (200+ spills), so the last NEB - 8 blocks of z' are parked in LDS (wave-private, 16 KiB per wave: with the
+//       96 KiB ring exactly the 160 KiB of a CU) and fetched for the one split and the one residual add they see per layer.
+//       (Halving the hidden layer instead is not an option: the second half's up-projection needs the block's INPUT z'.)
+//   y   NHB x 16 AGPRs: the up-projection's chain accumulators (K-outer order: all NHB chains advance together, so no two
+//       consecutive MFMAs depend on each other), converted IN PLACE (relu, scale, split) into the fp16 hi / lo B operands of
+//       the down-projection (16 fp32 = 8 + 8 packed registers)
+//   t   two chain accumulators for the down-projection (a pair of output blocks at a time, hi/lo products interleaved)
+// Weight stream: fragments of 1 KiB = one MFMA A operand (32 features x 16 k x fp16) in consumption order -- per pair of
+// output blocks (o, o+1) and K-chunk: hi(o), lo(o), hi(o+1), lo(o+1) -- through the workgroup-shared LDS-DMA ring, read one
+// quad (4 fragments = 6 MFMAs = 192 cycles) ahead; the ring turns over 5.3x faster than in the fp32 kernel, so the barrier /
+// refill cadence is a group of 16 fragments (each wave DMAs 4), measured best in scripts/ubench/split16.hip.
+#pragma once
+#include "mlp_kernel.hpp"
+
+namespace qinco {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define QINCO_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// fp16 hi / lo parts of a 32-feature block of one row tile, as the two K = 16 chunks' B operands.  A lane's 16 values are
+// registers r = 0..15 of the 32x32 C/D layout; chunk c takes r = 8c .. 8c+7 (the host packs the weights' K order to match).
+struct SplitBlock {
+  f16x8 h[2], l[2];
+};
+
+QINCO_INL SplitBlock split_block(const f32x16& v) {
+  SplitBlock s;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const _Float16 hi = (_Float16)v[8 * c + i];   // round to nearest even
+      s.h[c][i] = hi;
+      s.l[c][i] = (_Float16)(v[8 * c + i] - (float)hi);   // exact difference, then rounded
+    }
+  return s;
+}
+
+template <int D, int DE, int DH, int P>
+__global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
+  constexpr StreamDims SL = stream_dims(D, DE, DH, P, true, true);
+  constexpr int NDB = SL.NDB, NEB = SL.NEB, NHB = SL.NHB;
+  constexpr bool PROJ = SL.PROJ;
+  constexpr int NZV = NEB > 8 ? 8 : NEB, NPARK = NEB - NZV;   // z blocks in registers / parked in LDS
+  constexpr int G = 16, NG = P / G, PER = G / 4;   // ring group (barrier / refill cadence), groups in the ring, DMAs per wave
+  constexpr int T_UPS = round_up(NHB * NEB * 4, P), T_DOWNS = round_up(NEB * NHB * 4, P);
+  static_assert(P % G == 0 && NG >= 4, "ring: at least 4 groups of 16 fragments");
+  static_assert(NEB % 2 == 0 && NHB % 2 == 0 && NZV % 2 == 0, "output blocks are processed in pairs");
+  static_assert(T_UPS == SL.T_UP && T_DOWNS == SL.T_DOWN, "same section sizes as the fp32 kernel's stream");
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 31, half = lane >> 5;
+  const long tile = (long)blockIdx.x * 4 + wave;
+  long row = tile * 32 + j;      // every wave runs (barriers); rows past R are clamped and never stored
+  const bool valid = row < a.R;
+  if (!valid) row = a.R - 1;
+  const long g = row / a.A;
+  const int cid = a.cand_ids ? a.cand_ids[row] : (int)(row - g * a.A);
+  const float* cptr = a.codebook + (long)cid * D + half * 4;
+  const float* xhptr = a.xhat + g * D + half * 4;
+
+  // ---- weight ring ------------------------------------------------------------------------------------
+  __shared__ f32x4 lds_ring[P * 64];
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const f32x4* wsrc = a.wstream + lane + wave_u * PER * 64;   // origin of the current section (sections are multiples of P)
+  f32x4* wdst = lds_ring + wave_u * PER * 64;                 // ... + this wave's share of a group
+  auto dma_group = [&]<int T0>() QINCO_LAMBDA {            // fragments T0 .. T0+15 of the section -> their ring slots
+    static_for<PER>([&]<int q>() QINCO_LAMBDA {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (T0 + q) * 64),
+                                       (__attribute__((address_space(3))) void*)(wdst + ((T0 + q) % P) * 64), 16, 0, 0);
+    });
+  };
+  static_for<NG - 1>([&]<int i>() QINCO_LAMBDA { dma_group.template operator()<i * G>(); });
+  // Quad T .. T+3 of the current section -> dst.  At a group boundary: every LDS read this wave has issued -- the previous
+  // group's -- has completed (lgkmcnt(0); hipcc would otherwise let that wait, and the MFMAs behind it, sink below the barrier
+  // that lets the other waves refill the group: mlp_kernel.hpp, fragmm), this wave's DMAs of the new group have landed (it
+  // has issued NG-1 groups beyond the ones already consumed, so "at most (NG-2) x PER outstanding" means the oldest of them
+  // is complete; younger loads / stores of the wave only make the wait stricter), and past the barrier the previous
+  // group's slots are refilled with the group NG-1 ahead.
+  auto ldquad = [&]<int T>(f32x4 (&dst)[4]) QINCO_LAMBDA {
+    if constexpr (T % G == 0) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0070 | (((NG - 2) * PER) & 15) | ((((NG - 2) * PER) >> 4) << 14));   // vmcnt(N) + lgkmcnt(0)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      dma_group.template operator()<T + P - G>();
+    }
+    static_for<4>([&]<int q>() QINCO_LAMBDA { dst[q] = lds_ring[((T + q) % P) * 64 + lane]; });
+    asm volatile("" ::: "memory");
+  };
+  auto as16 = [](const f32x4& v) QINCO_LAMBDA { return __builtin_bit_cast(f16x8, v); };
+
+  const float zs = a.smul[0], zsi = a.smul[1];
+
+  // ---- z': blocks < NZV in registers, the others in this wave's LDS park (lane-linear float4 quarters: conflict free) ----
+  __shared__ f32x4 zpark[NPARK > 0 ? 4 * NPARK * 4 * 64 : 1];
+  f32x4* zp = zpark + (wave_u * NPARK * 4) * 64 + lane;
+  f32x16 z[NZV];
+  auto zget = [&]<int ob>() QINCO_LAMBDA -> f32x16 {
+    if constexpr (ob < NZV) {
+      return z[ob];
+    } else {
+      f32x16 v;
+      static_for<4>([&]<int q>() QINCO_LAMBDA {
+        const f32x4 t = zp[((ob - NZV) * 4 + q) * 64];
+        static_for<4>([&]<int e>() QINCO_LAMBDA { v[4 * q + e] = t[e]; });
+      });
+      return v;
+    }
+  };
+  auto zset = [&]<int ob>(const f32x16& v) QINCO_LAMBDA {
+    if constexpr (ob < NZV) {
+      z[ob] = v;
+      pin_v(z[ob]);
+    } else {
+      static_for<4>([&]<int q>() QINCO_LAMBDA {
+        const f32x4 t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        zp[((ob - NZV) * 4 + q) * 64] = t;
+      });
+    }
+  };
+
+  // ---- head: z' = 2^c (T[cid] + U[group]) ------------------------------------------------------------------
+  f32x16 y[NHB];     // up-projection accumulators, then (bit pattern of) SplitBlock
+  {
+    const float* tptr = a.ttab + (long)cid * DE + half * 4;
+    const float* uptr = a.uproj + g * DE + half * 4;
+    static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+      zset.template operator()<ob>((load_block(tptr + ob * 32) + load_block(uptr + ob * 32)) * zs);
+    });
+    // FFN block 0's hidden layer is folded: h = relu(P[cid] + Q[group]); y = split(2^a h)
+    const float* pptr = a.ptab + (long)cid * DH + half * 4;
+    const float* qptr = a.qproj + g * DH + half * 4;
+    const float m0 = a.smul[2];
+    static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
+      f32x16 v = load_block(pptr + ob * 32) + load_block(qptr + ob * 32);
+      relu16(v);
+      y[ob] = __builtin_bit_cast(f32x16, split_block(v * m0));
+      pin_a(y[ob]);
+    });
+  }
+
+  f32x4 cur[4], nxt[4];
+  ldquad.template operator()<0>(cur);
+
+  // one quad = hi(o), lo(o), hi(o+1), lo(o+1) for one K-chunk: six MFMAs, the two chains interleaved
+  auto quad_mm = [&](f32x16& t0, f32x16& t1, const f16x8& bh, const f16x8& bl) QINCO_LAMBDA {
+    t0 = QINCO_MFMA_H(as16(cur[0]), bh, t0);
+    t1 = QINCO_MFMA_H(as16(cur[2]), bh, t1);
+    t0 = QINCO_MFMA_H(as16(cur[0]), bl, t0);
+    t1 = QINCO_MFMA_H(as16(cur[2]), bl, t1);
+    t0 = QINCO_MFMA_H(as16(cur[1]), bh, t0);
+    t1 = QINCO_MFMA_H(as16(cur[3]), bh, t1);
+  };
+  auto advance = [&]() QINCO_LAMBDA {
+    static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
+  };
+  // the rest of a section (padding up to a multiple of P): read and drop, the ring protocol keeps running
+  auto end_section = [&]<int FROM, int TO>() QINCO_LAMBDA {
+    static_for<(TO - FROM) / 4>([&]<int i>() QINCO_LAMBDA {
+      ldquad.template operator()<FROM + 4 * i + 4>(nxt);
+      advance();
+    });
+    wsrc += TO * 64;
+  };
+
+  // ---- down-projection: z' += 2^(c-a-b) W_down' . h'   (output-pair outer, y complete) -----------
+  auto down_phase = [&](float mdn) QINCO_LAMBDA {
+    static_for<NEB / 2>([&]<int og>() QINCO_LAMBDA {
+      f32x16 t0 = zero16(), t1 = zero16();
+      static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
+        const SplitBlock s = __builtin_bit_cast(SplitBlock, y[ib]);
+        static_for<2>([&]<int c>() QINCO_LAMBDA {
+          constexpr int T = ((og * NHB + ib) * 2 + c) * 4;
+          ldquad.template operator()<T + 4>(nxt);
+          quad_mm(t0, t1, s.h[c], s.l[c]);
+          advance();
+        });
+      });
+      zset.template operator()<2 * og>(zget.template operator()<2 * og>() + t0 * mdn);
+      zset.template operator()<2 * og + 1>(zget.template operator()<2 * og + 1>() + t1 * mdn);
+    });
+    end_section.template operator()<NEB * NHB * 4, T_DOWNS>();
+  };
+  // ---- up-projection: y = split(2^(a-c-d) relu(W_up' . z'))   (K-outer: every chain advances by one K-chunk per pass) ----
+  auto up_phase = [&](float mup) QINCO_LAMBDA {
+    static_for<NHB>([&]<int ob>() QINCO_LAMBDA { y[ob] = zero16(); });
+    static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
+      const SplitBlock s = split_block(zget.template operator()<ib>());
+      static_for<2>([&]<int c>() QINCO_LAMBDA {
+        static_for<NHB / 2>([&]<int op>() QINCO_LAMBDA {
+          constexpr int T = ((ib * 2 + c) * (NHB / 2) + op) * 4;
+          ldquad.template operator()<T + 4>(nxt);
+          quad_mm(y[2 * op], y[2 * op + 1], s.h[c], s.l[c]);
+          advance();
+        });
+      });
+    });
+    static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
+      f32x16 v = y[ob];
+      relu16(v);
+      y[ob] = __builtin_bit_cast(f32x16, split_block(v * mup));
+      pin_a(y[ob]);
+    });
+    end_section.template operator()<NHB * NEB * 4, T_UPS>();
+  };
+
+  down_phase(a.smul[3]);   // block 0 (its up-projection is folded into P, Q)
+#pragma unroll 1
+  for (int l = 1; l < a.L; ++l) {
+    up_phase(a.smul[2 + 2 * l]);
+    down_phase(a.smul[3 + 2 * l]);
+  }
+
+  // ---- tail (fp32, as mlp_kernel.hpp E): out_proj + epilogue: cand = (out + coeff*c) + xhat ; dist = |x|^2 + |cand|^2 - 2 x.cand
+  const long n = g / a.F;
+  const float* xptr = a.x ? a.x + n * D + half * 4 : nullptr;
+  float* outp = a.cand_out + row * D + half * 4;
+  float s2 = 0.f, sx = 0.f, xn = 0.f;
+  static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
+    f32x16 cblk, xhb, xb;
+    if (a.add_c) cblk = load_block(cptr + ob * 32);
+    xhb = load_block(xhptr + ob * 32);
+    if (xptr) xb = load_block(xptr + ob * 32);
+    f32x16 o;
+    if constexpr (PROJ) {
+      o = zero16();
+      static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
+        constexpr int T = (ob * NEB + ib) * 4;     // fragments q = 0..3 of block pair (ob, ib): fp32 A operands, 4 MFMAs each
+        const f32x16 zb = zget.template operator()<ib>();
+        ldquad.template operator()<T + 4>(nxt);
+        static_for<4>([&]<int q>() QINCO_LAMBDA {
+          static_for<4>([&]<int e>() QINCO_LAMBDA { o = QINCO_MFMA(cur[q][e], zb[4 * q + e], o); });
+        });
+        advance();
+      });
+      o = o * zsi;
+    } else {
+      o = zget.template operator()<ob>() * zsi;
+    }
+    if (a.add_c) o = o + cblk;
+    o = o + xhb;
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 t = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(outp + ob * 32 + 8 * q) = t;
+      }
+    }
+    if (xptr) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s2 = fmaf(o[i], o[i], s2);
+        sx = fmaf(o[i], xb[i], sx);
+        xn = fmaf(xb[i], xb[i], xn);
+      }
+    }
+  });
+  if (a.dist_out) {
+    s2 += __shfl_xor(s2, 32);
+    sx += __shfl_xor(sx, 32);
+    xn += __shfl_xor(xn, 32);
+    if (valid && half == 0) a.dist_out[row] = (xn + s2) - 2.f * sx;
+  }
+  // no LDS-DMA may be in flight when the wave ends (its LDS could be handed to the next workgroup)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace qinco

@@ -87,6 +87,8 @@ struct qinco_handle_s {
   float* uproj = nullptr;      // (max_batch * B, De [+ Dh]) scratch: U_g = W_cat[:, De:] xhat_g  [then Q_g = W_up[0] U_g]
   float* duproj = nullptr;     // decode counterpart (dec_cap, De [+ Dh])
   std::vector<f32x4*> wstream;
+  bool split16 = false;             // split-fp16 FFN blocks (QINCO_FLAG_SPLIT_F16; mlp_split_kernel.hpp)
+  std::vector<float*> smul;         // per step: [2^c, 2^-c, m_up[0], m_down[0], m_up[1], ...]
   // decode runs one row per group: nothing to share, so the folded head only adds the xproj launch and the U / Q round trip
   // through HBM.  When the shape has an un-folded instance, decode uses it with its own (complete) weight stream.
   const MlpInstance* dec_inst = nullptr;
@@ -248,6 +250,54 @@ static void pack16_bias(std::vector<float>& s, const float* b, int O, int T) {
       for (int r = 0; r < 4; ++r) s[base + l * 4 + r] = b[ob * 16 + 4 * (l >> 4) + r];
   }
   pad_to(s, start, T);
+}
+
+// Split-fp16 form (mlp_split_kernel.hpp): fragment = the A operand of one v_mfma_f32_32x32x16_f16, 32 output features x 16
+// inputs as fp16: lane l, element i = fp16 part of  scale * W[o*32 + (l & 31)][ib*32 + (i & 3) + 8 (2c + (i >> 2)) + 4 (l >> 5)]
+// -- K-chunk c of input block ib in the register order of the 32x32 C/D layout (registers 8c .. 8c+7 of a lane).  hi = fp16(v)
+// (round to nearest even), lo = fp16(v - hi).
+static void put_split_frags(std::vector<float>& s, const float* W, int I, int o, int ib, int c, float scale) {
+  size_t base = s.size();
+  s.resize(base + 512);   // hi fragment, then lo fragment
+  _Float16* hi = reinterpret_cast<_Float16*>(s.data() + base);
+  _Float16* lo = reinterpret_cast<_Float16*>(s.data() + base + 256);
+  for (int l = 0; l < 64; ++l)
+    for (int i = 0; i < 8; ++i) {
+      const float v = scale * W[(size_t)(o * 32 + (l & 31)) * I + ib * 32 + (i & 3) + 8 * (2 * c + (i >> 2)) + 4 * (l >> 5)];
+      const _Float16 h = (_Float16)v;
+      hi[l * 8 + i] = h;
+      lo[l * 8 + i] = (_Float16)(v - (float)h);
+    }
+}
+
+// up-projection (Dh x De), hidden half hh of nhs: K-outer -- for ib: for c: for each pair of hidden blocks: hi, lo, hi, lo
+static void pack_split_up(std::vector<float>& s, const float* W, int O, int I, int hh, int nhs, float scale, int T) {
+  size_t start = s.size();
+  const int noh = O / 32 / nhs;
+  for (int ib = 0; ib < I / 32; ++ib)
+    for (int c = 0; c < 2; ++c)
+      for (int o = 0; o < noh; ++o) put_split_frags(s, W, I, hh * noh + o, ib, c, scale);
+  pad_to(s, start, T);
+}
+
+// down-projection (De x Dh), hidden half hh: for each pair of output blocks: for ib (of the half): for c: hi, lo, hi, lo
+static void pack_split_down(std::vector<float>& s, const float* W, int O, int I, int hh, int nhs, float scale, int T) {
+  size_t start = s.size();
+  const int nih = I / 32 / nhs;
+  for (int og = 0; og < O / 64; ++og)
+    for (int ib = 0; ib < nih; ++ib)
+      for (int c = 0; c < 2; ++c)
+        for (int o = 2 * og; o < 2 * og + 2; ++o) put_split_frags(s, W, I, o, hh * nih + ib, c, scale);
+  pad_to(s, start, T);
+}
+
+// 2^e with max |scale * W| in [512, 1024): every weight down to 2^-11 of the largest keeps a normal fp16 lo part (>= 2^-14)
+// and nothing comes near the fp16 maximum (65504).
+static float split_weight_scale(const float* W, size_t n) {
+  float mx = 0.f;
+  for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(W[i]));
+  if (!(mx > 0.f) || !std::isfinite(mx)) return 1.f;
+  return ldexpf(1.f, 9 - ilogbf(mx));
 }
 
 static int upload(qinco_handle_s* h, float** dst, const float* src, size_t count) {
@@ -476,7 +526,14 @@ extern "C" int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh) {
 }
 
 extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinco_handle* out) {
+  // QINCO_SPLIT_F16=1: experiments / A-B runs of an unmodified caller
+  const char* e = getenv("QINCO_SPLIT_F16");
+  return qinco_create_ex(desc, w, (e && atoi(e) > 0) ? QINCO_CREATE_SPLIT_F16 : 0, out);
+}
+
+extern "C" int qinco_create_ex(const qinco_desc* desc, const qinco_weights* w, int32_t create_flags, qinco_handle* out) {
   if (!desc || !w || !out) return fail(QINCO_ERR_INVALID, "qinco_create: null argument");
+  if (create_flags & ~QINCO_CREATE_SPLIT_F16) return fail(QINCO_ERR_INVALID, "qinco_create_ex: unknown flag bits 0x%x", create_flags);
   const qinco_desc& d = *desc;
   if (d.D <= 0 || d.De <= 0 || d.Dh <= 0 || d.M <= 0 || d.K <= 0 || d.L < 0 || d.max_batch <= 0)
     return fail(QINCO_ERR_INVALID, "qinco_create: non-positive hyper-parameter");
@@ -493,6 +550,19 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   int want_P = -1, want_var = -1;  // A/B hook: QINCO_MLP_VARIANT="P,VAR" selects a non-production instance
   if (const char* ev = getenv("QINCO_MLP_VARIANT")) sscanf(ev, "%d,%d", &want_P, &want_var);
   const MlpInstance* fn = find_mlp_instance(d.D, d.De, d.Dh, want_P, want_var);
+  if ((create_flags & QINCO_CREATE_SPLIT_F16) && d.M > 1) {
+    // the split-fp16 instance of the shape (VAR bit 512); it peels FFN block 0 like FOLD2, so the model needs L >= 1
+    const MlpInstance* sp = nullptr;
+    for (int pp : {96, 48})
+      if (!sp) {
+        const MlpInstance* c = find_mlp_instance(d.D, d.De, d.Dh, pp, 512 | 124);
+        if (c && c->P == pp && c->var == (512 | 124)) sp = c;
+      }
+    if (!sp || d.L < 1)
+      return fail(QINCO_ERR_UNSUPPORTED, "qinco_create_ex: no split-fp16 kernel instance for (D=%d, De=%d, Dh=%d, L=%d)", d.D, d.De,
+                  d.Dh, d.L);
+    fn = sp;
+  }
   if (!fn && d.M > 1)
     return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: no fused-MLP kernel instance for (D=%d, De=%d, Dh=%d); add it to csrc/shapes.def",
                 d.D, d.De, d.Dh);
@@ -521,6 +591,8 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   }
   h->fold = fn && (fn->var & 16);
   h->fold2 = fn && (fn->var & 32);
+  h->split16 = fn && (fn->var & 512);
+  if (h->split16 && d.L < 1) return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: the split-fp16 kernel needs L >= 1");
   const bool tile16 = fn && (fn->var & 128);
   h->sd = stream_dims(d.D, d.De, d.Dh, kRing, h->fold, h->fold2, tile16 ? 16 : 32);
   if (h->fold && !getenv("QINCO_DECODE_FOLDED")) {
@@ -550,6 +622,7 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
   h->ptab.assign(d.M, nullptr);
   h->wx_stream.assign(d.M, nullptr);
   h->wq_stream.assign(d.M, nullptr);
+  h->smul.assign(d.M, nullptr);
   h->K0 = d.ivf_K > 0 ? d.ivf_K : d.K;
   std::vector<int> kv(d.M, d.K);
   kv[0] = h->K0;
@@ -602,13 +675,35 @@ extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinc
       pack_bias(s, w->cat_b[m], d.De, sd.T_BIAS);
       pack_kouter(s, w->cat_w[m], d.De, d.De + d.D, sd.T_CAT);
     }
+    std::vector<float> smul;
+    if (h->split16) {
+      // z' = 2^c z, h' = 2^a h (c = a = 3: values of O(1) sit around 8, their fp16 lo parts around 2^-9 -- normal --, and
+      // nothing below |v| = 2^16 / 8 overflows fp16); W' = scale * W per layer.  Epilogue multipliers (exact powers of two):
+      //   up:   h' = m_up relu(acc),   acc = W_up' z' = 2^(c+d) W_up z        -> m_up = 2^(a-c-d)     (block 0: h' = 2^a relu(P+Q))
+      //   down: z' += m_down acc,      acc = W_down' h' = 2^(a+b) W_down h    -> m_down = 2^(c-a-b)
+      const float zc = 8.f;
+      smul = {zc, 1.f / zc};
+    }
     for (int l = 0; l < d.L && !tile16; ++l) {
       const float* up = w->up[(size_t)m * d.L + l];
       const float* dn = w->down[(size_t)m * d.L + l];
       if (!up || !dn) return bail(fail(QINCO_ERR_INVALID, "qinco_create: FFN weights[%d][%d] null", m, l));
+      if (h->split16) {
+        const int nhs = 1;
+        const float su = split_weight_scale(up, (size_t)d.Dh * d.De), sdn = split_weight_scale(dn, (size_t)d.De * d.Dh);
+        const float zc = smul[0], ha = 8.f;
+        smul.push_back(l == 0 ? ha : ha / (zc * su));
+        smul.push_back(zc / (ha * sdn));
+        for (int hh = 0; hh < nhs; ++hh) {
+          if (l > 0) pack_split_up(s, up, d.Dh, d.De, hh, nhs, su, sd.T_UP / nhs);
+          pack_split_down(s, dn, d.De, d.Dh, hh, nhs, sdn, sd.T_DOWN / nhs);
+        }
+        continue;
+      }
       if (!(h->fold2 && l == 0)) pack_obouter(s, up, d.Dh, d.De, sd.T_UP);
       pack_obouter(s, dn, d.De, d.Dh, sd.T_DOWN);
     }
+    if (h->split16 && (rc = upload(h, &h->smul[m], smul.data(), smul.size()))) return bail(rc);
     if (sd.PROJ && !tile16) pack_obouter(s, w->out_proj[m], d.D, d.De, sd.T_OUT);
     if ((long)(s.size() / 256) != sd.total(d.L)) return bail(fail(QINCO_ERR_INVALID, "internal: stream size mismatch"));
     s.resize(s.size() + (size_t)kRing * 256, 0.f);  // the ring prefetches P fragments past the end
@@ -710,6 +805,7 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
     HIP_TRY(h->inst->xproj(&xa, st));
     a.ttab = h->ttab[m];
   }
+  a.smul = h->split16 ? h->smul[m] : nullptr;
 #ifdef QINCO_TIMELINE
   {
     const size_t tiles = (size_t)((a.R + 31) / 32 + 4);

@@ -24,9 +24,13 @@ class QincoEngine:
     are accepted (PyTorch is only the weight loader here).
     """
 
-    def __init__(self, cfg: QincoConfig, state_dict: dict, max_batch: int = 8192, device: Optional[int] = None):
+    def __init__(self, cfg: QincoConfig, state_dict: dict, max_batch: int = 8192, device: Optional[int] = None,
+                 split_f16: bool = False):
+        """split_f16: opt-in split-fp16 evaluation of the FFN blocks (include/qinco_hip.h, QINCO_CREATE_SPLIT_F16): several
+        times the fp32-MFMA throughput, fp32-class accuracy but not the fp32 path's bits."""
         self.lib = _lib.load()
         self.cfg = cfg
+        self.split_f16 = bool(split_f16)
         self.max_batch = int(max_batch)
         self._h = C.c_void_p()
         if device is not None:
@@ -82,7 +86,10 @@ class QincoEngine:
         w.cat_w, w.cat_b, w.up, w.down = cw, cbias, up, down
         desc = _lib.QincoDesc(D=D, De=De, Dh=Dh, L=L, M=M, K=K, A=cfg.A, B=cfg.B,
                               qinco1_mode=int(cfg.qinco1_mode), ivf_K=int(cfg.ivf_K or 0), max_batch=self.max_batch)
-        _lib.check(self.lib.qinco_create(C.byref(desc), C.byref(w), C.byref(self._h)))
+        if self.split_f16:
+            _lib.check(self.lib.qinco_create_ex(C.byref(desc), C.byref(w), _lib.CREATE_SPLIT_F16, C.byref(self._h)))
+        else:
+            _lib.check(self.lib.qinco_create(C.byref(desc), C.byref(w), C.byref(self._h)))
         self._keep = []  # weights now live on the device
         self.data_mean = sd["data_mean"]
         self.data_std = F32(std)

@@ -19,10 +19,11 @@ from .engine import QincoEngine, _is_torch
 
 class QINCoHIP:
     def __init__(self, cfg: QincoConfig, state_dict: Optional[dict] = None, max_batch: int = 8192,
-                 device: Optional[int] = None):
+                 device: Optional[int] = None, split_f16: bool = False):
         self.cfg = cfg
         self.max_batch = max_batch
         self.device = device
+        self.split_f16 = split_f16   # opt-in: QincoEngine(split_f16=...)
         self.built = False
         self.engine: Optional[QincoEngine] = None
         self._sd: Optional[dict] = None
@@ -47,7 +48,8 @@ class QINCoHIP:
             raise AssertionError("data_std must be > 0")  # qinco_base.py:526
         if self.engine is not None:
             self.engine.close()
-        self.engine = QincoEngine(self.cfg, self._sd, max_batch=self.max_batch, device=self.device)
+        self.engine = QincoEngine(self.cfg, self._sd, max_batch=self.max_batch, device=self.device,
+                                  split_f16=self.split_f16)
         self.data_mean = self._sd["data_mean"]
         self.data_std = self._sd["data_std"]
         self.built = True

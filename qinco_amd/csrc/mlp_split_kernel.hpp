@@ -55,6 +55,22 @@ QINCO_INL SplitBlock split_block(const f32x16& v) {
   return s;
 }
 
+// LDS accesses as inline asm.  hipcc orders every LDS instruction it can see behind ALL LDS-DMAs in flight (s_waitcnt vmcnt(0)
+// in front of the first ds_read after each refill: SIInsertWaitcnts cannot tell which bytes a global_load_lds writes) --
+// that would expose the full L2 latency once per group of 16 fragments.  The ring protocol below is the real ordering; the
+// price of going behind the compiler's back is that the arrival of these reads is ours to wait for (lds_arrived*).
+template <int OFF>
+QINCO_INL void lds_read128(f32x4& v, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+QINCO_INL void lds_write128(unsigned addr, const f32x4& v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+QINCO_INL void lds_arrived4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
 template <int D, int DE, int DH, int P>
 __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   constexpr StreamDims SL = stream_dims(D, DE, DH, P, true, true);
@@ -91,6 +107,8 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
     });
   };
   static_for<NG - 1>([&]<int i>() QINCO_LAMBDA { dma_group.template operator()<i * G>(); });
+  const unsigned ring_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds_ring + lane * 16;
+  const unsigned ring_addr_hi = ring_addr + 48 * 1024;   // (the offset field of a DS instruction is 16 bits)
   // Quad T .. T+3 of the current section -> dst.  At a group boundary: every LDS read this wave has issued -- the previous
   // group's -- has completed (lgkmcnt(0); hipcc would otherwise let that wait, and the MFMAs behind it, sink below the barrier
   // that lets the other waves refill the group: mlp_kernel.hpp, fragmm), this wave's DMAs of the new group have landed (it
@@ -105,8 +123,10 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
       __builtin_amdgcn_s_barrier();
       dma_group.template operator()<T + P - G>();
     }
-    static_for<4>([&]<int q>() QINCO_LAMBDA { dst[q] = lds_ring[((T + q) % P) * 64 + lane]; });
-    asm volatile("" ::: "memory");
+    static_for<4>([&]<int q>() QINCO_LAMBDA {
+      constexpr int slot = (T + q) % P;
+      if constexpr (slot < 48) lds_read128<slot * 1024>(dst[q], ring_addr); else lds_read128<(slot - 48) * 1024>(dst[q], ring_addr_hi);
+    });
   };
   auto as16 = [](const f32x4& v) QINCO_LAMBDA { return __builtin_bit_cast(f16x8, v); };
 
@@ -114,16 +134,18 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
 
   // ---- z': blocks < NZV in registers, the others in this wave's LDS park (lane-linear float4 quarters: conflict free) ----
   __shared__ f32x4 zpark[NPARK > 0 ? 4 * NPARK * 4 * 64 : 1];
-  f32x4* zp = zpark + (wave_u * NPARK * 4) * 64 + lane;
+  const unsigned zp_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)zpark + (wave_u * NPARK * 4 * 64 + lane) * 16;
   f32x16 z[NZV];
   auto zget = [&]<int ob>() QINCO_LAMBDA -> f32x16 {
     if constexpr (ob < NZV) {
       return z[ob];
     } else {
+      f32x4 t[4];
+      static_for<4>([&]<int q>() QINCO_LAMBDA { lds_read128<((ob - NZV) * 4 + q) * 1024>(t[q], zp_addr); });
+      lds_arrived4(t[0], t[1], t[2], t[3]);
       f32x16 v;
       static_for<4>([&]<int q>() QINCO_LAMBDA {
-        const f32x4 t = zp[((ob - NZV) * 4 + q) * 64];
-        static_for<4>([&]<int e>() QINCO_LAMBDA { v[4 * q + e] = t[e]; });
+        static_for<4>([&]<int e>() QINCO_LAMBDA { v[4 * q + e] = t[q][e]; });
       });
       return v;
     }
@@ -135,7 +157,7 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
     } else {
       static_for<4>([&]<int q>() QINCO_LAMBDA {
         const f32x4 t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-        zp[((ob - NZV) * 4 + q) * 64] = t;
+        lds_write128<((ob - NZV) * 4 + q) * 1024>(zp_addr, t);
       });
     }
   };
@@ -162,74 +184,97 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
 
   f32x4 cur[4], nxt[4];
   ldquad.template operator()<0>(cur);
+  lds_arrived4(cur[0], cur[1], cur[2], cur[3]);
 
-  // one quad = hi(o), lo(o), hi(o+1), lo(o+1) for one K-chunk: six MFMAs, the two chains interleaved
-  auto quad_mm = [&](f32x16& t0, f32x16& t1, const f16x8& bh, const f16x8& bl) QINCO_LAMBDA {
+  // One step = one quad = hi(o), lo(o), hi(o+1), lo(o+1) for one K-chunk: the next quad's LDS reads are issued, then the six
+  // MFMAs of the current one (the two chains interleaved) plus `extra` -- VALU work of a neighbouring stage that the MFMAs do not
+  // depend on --, then the next quad must have arrived.  The scheduling barriers keep the MFMAs between the reads and the wait
+  // (hipcc hoists them above the reads otherwise and the wait then exposes the LDS latency in every step).
+  auto noop = []() QINCO_LAMBDA {};
+  auto step = [&]<int TN>(f32x16& t0, f32x16& t1, const f16x8& bh, const f16x8& bl, auto&& extra) QINCO_LAMBDA {
+    ldquad.template operator()<TN>(nxt);
+    __builtin_amdgcn_sched_barrier(0);
     t0 = QINCO_MFMA_H(as16(cur[0]), bh, t0);
     t1 = QINCO_MFMA_H(as16(cur[2]), bh, t1);
     t0 = QINCO_MFMA_H(as16(cur[0]), bl, t0);
     t1 = QINCO_MFMA_H(as16(cur[2]), bl, t1);
     t0 = QINCO_MFMA_H(as16(cur[1]), bh, t0);
     t1 = QINCO_MFMA_H(as16(cur[3]), bh, t1);
-  };
-  auto advance = [&]() QINCO_LAMBDA {
+    extra();
+    __builtin_amdgcn_sched_barrier(0);
+    lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
     static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
   };
   // the rest of a section (padding up to a multiple of P): read and drop, the ring protocol keeps running
   auto end_section = [&]<int FROM, int TO>() QINCO_LAMBDA {
     static_for<(TO - FROM) / 4>([&]<int i>() QINCO_LAMBDA {
       ldquad.template operator()<FROM + 4 * i + 4>(nxt);
-      advance();
+      lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
+      static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
     });
     wsrc += TO * 64;
   };
+  // accumulators of hidden block ob -> B operands of the down-projection, in place
+  auto convert_y = [&]<int ob>(float mup) QINCO_LAMBDA {
+    f32x16 v = y[ob];
+    relu16(v);
+    y[ob] = __builtin_bit_cast(f32x16, split_block(v * mup));
+    pin_a(y[ob]);
+  };
 
-  // ---- down-projection: z' += 2^(c-a-b) W_down' . h'   (output-pair outer, y complete) -----------
-  auto down_phase = [&](float mdn) QINCO_LAMBDA {
+  // ---- down-projection: z' += 2^(c-a-b) W_down' . h'   (output-pair outer) -------------------------------------------
+  // LAZY (after an up-projection): only y[0] is converted on entry; block ib+1's conversion rides on the first pair's step
+  // (ib, 0).  The residual add of pair og-1 rides on pair og's first step (two alternating accumulator pairs), so that only the
+  // last chain end of the phase drains the matrix pipe.
+  auto down_phase = [&]<bool LAZY>(float mdn, float mup) QINCO_LAMBDA {
+    f32x16 t[2][2];
+    auto residual = [&]<int og>() QINCO_LAMBDA {
+      zset.template operator()<2 * og>(zget.template operator()<2 * og>() + t[og & 1][0] * mdn);
+      zset.template operator()<2 * og + 1>(zget.template operator()<2 * og + 1>() + t[og & 1][1] * mdn);
+    };
     static_for<NEB / 2>([&]<int og>() QINCO_LAMBDA {
-      f32x16 t0 = zero16(), t1 = zero16();
+      t[og & 1][0] = zero16();
+      t[og & 1][1] = zero16();
       static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
-        const SplitBlock s = __builtin_bit_cast(SplitBlock, y[ib]);
         static_for<2>([&]<int c>() QINCO_LAMBDA {
           constexpr int T = ((og * NHB + ib) * 2 + c) * 4;
-          ldquad.template operator()<T + 4>(nxt);
-          quad_mm(t0, t1, s.h[c], s.l[c]);
-          advance();
+          const SplitBlock s = __builtin_bit_cast(SplitBlock, y[ib]);
+          step.template operator()<T + 4>(t[og & 1][0], t[og & 1][1], s.h[c], s.l[c], [&]() QINCO_LAMBDA {
+            if constexpr (LAZY && og == 0 && c == 0 && ib + 1 < NHB) convert_y.template operator()<ib + 1>(mup);
+            if constexpr (og > 0 && ib == 0 && c == 0) residual.template operator()<og - 1>();
+          });
         });
       });
-      zset.template operator()<2 * og>(zget.template operator()<2 * og>() + t0 * mdn);
-      zset.template operator()<2 * og + 1>(zget.template operator()<2 * og + 1>() + t1 * mdn);
     });
+    residual.template operator()<NEB / 2 - 1>();
     end_section.template operator()<NEB * NHB * 4, T_DOWNS>();
   };
-  // ---- up-projection: y = split(2^(a-c-d) relu(W_up' . z'))   (K-outer: every chain advances by one K-chunk per pass) ----
+  // ---- up-projection: y = W_up' . z'   (K-outer: every chain advances by one K-chunk per pass; the split of input block
+  //      ib+1 rides on block ib's first steps).  The conversion of y belongs to the down-projection that follows. ----
   auto up_phase = [&](float mup) QINCO_LAMBDA {
     static_for<NHB>([&]<int ob>() QINCO_LAMBDA { y[ob] = zero16(); });
+    SplitBlock sb[2];
+    sb[0] = split_block(zget.template operator()<0>());
     static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
-      const SplitBlock s = split_block(zget.template operator()<ib>());
       static_for<2>([&]<int c>() QINCO_LAMBDA {
         static_for<NHB / 2>([&]<int op>() QINCO_LAMBDA {
           constexpr int T = ((ib * 2 + c) * (NHB / 2) + op) * 4;
-          ldquad.template operator()<T + 4>(nxt);
-          quad_mm(y[2 * op], y[2 * op + 1], s.h[c], s.l[c]);
-          advance();
+          step.template operator()<T + 4>(y[2 * op], y[2 * op + 1], sb[ib & 1].h[c], sb[ib & 1].l[c], [&]() QINCO_LAMBDA {
+            if constexpr (c == 0 && op == 0 && ib + 1 < NEB) sb[(ib + 1) & 1] = split_block(zget.template operator()<ib + 1>());
+          });
         });
       });
     });
-    static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
-      f32x16 v = y[ob];
-      relu16(v);
-      y[ob] = __builtin_bit_cast(f32x16, split_block(v * mup));
-      pin_a(y[ob]);
-    });
+    convert_y.template operator()<0>(mup);
     end_section.template operator()<NHB * NEB * 4, T_UPS>();
   };
 
-  down_phase(a.smul[3]);   // block 0 (its up-projection is folded into P, Q)
+  down_phase.template operator()<false>(a.smul[3], 0.f);   // block 0 (its up-projection is folded into P, Q)
 #pragma unroll 1
   for (int l = 1; l < a.L; ++l) {
-    up_phase(a.smul[2 + 2 * l]);
-    down_phase(a.smul[3 + 2 * l]);
+    const float mup = a.smul[2 + 2 * l];
+    up_phase(mup);
+    down_phase.template operator()<true>(a.smul[3 + 2 * l], mup);
   }
 
   // ---- tail (fp32, as mlp_kernel.hpp E): out_proj + epilogue: cand = (out + coeff*c) + xhat ; dist = |x|^2 + |cand|^2 - 2 x.cand
@@ -249,10 +294,13 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
         constexpr int T = (ob * NEB + ib) * 4;     // fragments q = 0..3 of block pair (ob, ib): fp32 A operands, 4 MFMAs each
         const f32x16 zb = zget.template operator()<ib>();
         ldquad.template operator()<T + 4>(nxt);
+        __builtin_amdgcn_sched_barrier(0);
         static_for<4>([&]<int q>() QINCO_LAMBDA {
           static_for<4>([&]<int e>() QINCO_LAMBDA { o = QINCO_MFMA(cur[q][e], zb[4 * q + e], o); });
         });
-        advance();
+        __builtin_amdgcn_sched_barrier(0);
+        lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
+        static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
       });
       o = o * zsi;
     } else {

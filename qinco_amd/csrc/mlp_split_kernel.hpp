@@ -90,6 +90,14 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   long row = tile * 32 + j;      // every wave runs (barriers); rows past R are clamped and never stored
   const bool valid = row < a.R;
   if (!valid) row = a.R - 1;
+#ifdef QINCO_TIMELINE
+  auto stamp = [&](int i) QINCO_LAMBDA {
+    if (a.timeline && lane == 0) a.timeline[tile * 8 + i] = __builtin_readcyclecounter();
+  };
+#else
+  auto stamp = [](int) QINCO_LAMBDA {};
+#endif
+  stamp(0);
   const long g = row / a.A;
   const int cid = a.cand_ids ? a.cand_ids[row] : (int)(row - g * a.A);
   const float* cptr = a.codebook + (long)cid * D + half * 4;
@@ -128,6 +136,23 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
       if constexpr (slot < 48) lds_read128<slot * 1024>(dst[q], ring_addr); else lds_read128<(slot - 48) * 1024>(dst[q], ring_addr_hi);
     });
   };
+  // the same, in the pieces a step spreads between its MFMAs
+  auto ring_sync = [&]<int T>() QINCO_LAMBDA {
+    if constexpr (T % G == 0) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0070 | (((NG - 2) * PER) & 15) | ((((NG - 2) * PER) >> 4) << 14));
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  auto ring_piece = [&]<int T, int q>(f32x4& dst) QINCO_LAMBDA {
+    if constexpr (T % G == 0 && q < PER)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (T + P - G + q) * 64),
+                                       (__attribute__((address_space(3))) void*)(wdst + ((T + P - G + q) % P) * 64), 16, 0, 0);
+    constexpr int slot = (T + q) % P;
+    if constexpr (slot < 48) lds_read128<slot * 1024>(dst, ring_addr); else lds_read128<(slot - 48) * 1024>(dst, ring_addr_hi);
+  };
+  static_assert(PER <= 4, "a step carries at most four DMAs");
   auto as16 = [](const f32x4& v) QINCO_LAMBDA { return __builtin_bit_cast(f16x8, v); };
 
   const float zs = a.smul[0], zsi = a.smul[1];
@@ -183,25 +208,33 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   }
 
   f32x4 cur[4], nxt[4];
+  stamp(1);   // head operands assembled
   ldquad.template operator()<0>(cur);
   lds_arrived4(cur[0], cur[1], cur[2], cur[3]);
+  stamp(2);   // first quad of the stream in registers
 
-  // One step = one quad = hi(o), lo(o), hi(o+1), lo(o+1) for one K-chunk: the next quad's LDS reads are issued, then the six
-  // MFMAs of the current one (the two chains interleaved) plus `extra` -- VALU work of a neighbouring stage that the MFMAs do not
-  // depend on --, then the next quad must have arrived.  The scheduling barriers keep the MFMAs between the reads and the wait
-  // (hipcc hoists them above the reads otherwise and the wait then exposes the LDS latency in every step).
+  // One step = one quad = hi(o), lo(o), hi(o+1), lo(o+1) for one K-chunk: the six MFMAs of the current quad (the two chains
+  // interleaved) with the next quad's ring traffic -- group boundary, one DMA and one LDS read per gap -- spread between them,
+  // plus `extra`: VALU work of a neighbouring stage that the MFMAs do not depend on; then the next quad must have arrived.
+  // Everything is pinned by scheduling barriers: left alone, hipcc hoists the MFMAs above the reads (the wait then exposes
+  // the LDS latency in every step), and a wave that issues its four reads and four DMAs in one go leaves the pipe idle.
   auto noop = []() QINCO_LAMBDA {};
   auto step = [&]<int TN>(f32x16& t0, f32x16& t1, const f16x8& bh, const f16x8& bl, auto&& extra) QINCO_LAMBDA {
-    ldquad.template operator()<TN>(nxt);
-    __builtin_amdgcn_sched_barrier(0);
-    t0 = QINCO_MFMA_H(as16(cur[0]), bh, t0);
-    t1 = QINCO_MFMA_H(as16(cur[2]), bh, t1);
-    t0 = QINCO_MFMA_H(as16(cur[0]), bl, t0);
-    t1 = QINCO_MFMA_H(as16(cur[2]), bl, t1);
-    t0 = QINCO_MFMA_H(as16(cur[1]), bh, t0);
+#define QINCO_SB __builtin_amdgcn_sched_barrier(0)
+    t0 = QINCO_MFMA_H(as16(cur[0]), bh, t0);  QINCO_SB;
+    ring_sync.template operator()<TN>();      QINCO_SB;
+    t1 = QINCO_MFMA_H(as16(cur[2]), bh, t1);  QINCO_SB;
+    ring_piece.template operator()<TN, 0>(nxt[0]);  QINCO_SB;
+    t0 = QINCO_MFMA_H(as16(cur[0]), bl, t0);  QINCO_SB;
+    ring_piece.template operator()<TN, 1>(nxt[1]);  QINCO_SB;
+    t1 = QINCO_MFMA_H(as16(cur[2]), bl, t1);  QINCO_SB;
+    ring_piece.template operator()<TN, 2>(nxt[2]);  QINCO_SB;
+    t0 = QINCO_MFMA_H(as16(cur[1]), bh, t0);  QINCO_SB;
+    ring_piece.template operator()<TN, 3>(nxt[3]);  QINCO_SB;
     t1 = QINCO_MFMA_H(as16(cur[3]), bh, t1);
     extra();
-    __builtin_amdgcn_sched_barrier(0);
+    QINCO_SB;
+#undef QINCO_SB
     lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
     static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
   };
@@ -270,6 +303,7 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   };
 
   down_phase.template operator()<false>(a.smul[3], 0.f);   // block 0 (its up-projection is folded into P, Q)
+  stamp(6);
 #pragma unroll 1
   for (int l = 1; l < a.L; ++l) {
     const float mup = a.smul[2 + 2 * l];
@@ -277,6 +311,7 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
     down_phase.template operator()<true>(a.smul[3 + 2 * l], mup);
   }
 
+  stamp(3);   // FFN blocks done
   // ---- tail (fp32, as mlp_kernel.hpp E): out_proj + epilogue: cand = (out + coeff*c) + xhat ; dist = |x|^2 + |cand|^2 - 2 x.cand
   const long n = g / a.F;
   const float* xptr = a.x ? a.x + n * D + half * 4 : nullptr;
@@ -330,8 +365,10 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
     xn += __shfl_xor(xn, 32);
     if (valid && half == 0) a.dist_out[row] = (xn + s2) - 2.f * sx;
   }
+  stamp(4);
   // no LDS-DMA may be in flight when the wave ends (its LDS could be handed to the next workgroup)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(5);
 }
 
 }  // namespace qinco

@@ -75,6 +75,7 @@ CASES = {
     "tiny_proj_greedyA": (QincoConfig(D=32, M=4, K=256, L=2, de=64, dh=96, A=8, B=1), 12, 256),
     "tiny_id_qinco1": (QincoConfig(D=32, M=4, K=256, L=2, de=None, dh=64, A=0, B=1, qinco1_mode=True), 13, 256),
     "tiny_id_A0_beam": (QincoConfig(D=32, M=3, K=256, L=1, de=None, dh=64, A=0, B=3, qinco1_mode=False), 14, 64),
+    "tiny_proj_dh128": (QincoConfig(D=32, M=4, K=256, L=3, de=64, dh=128, A=8, B=4), 18, 256),   # even block counts: the split-fp16 form
     "C1_qinco1_8x8": (preset("qinco1", D=128, M=8), 1235, 128),
     "C2_qinco2L_8x8_b8": (preset("qinco2-L", D=128, M=8, B=8), 1236, 64),
     "C2_qinco2L_8x8_b1": (preset("qinco2-L", D=128, M=8, B=1), 1236, 64),

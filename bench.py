@@ -23,7 +23,8 @@ fewer FLOPs than the algorithm counts: `frac_executed` = executed FLOPs / durati
 (it cannot exceed 1; the algorithmic one can on short models).
 Also in the line (N = 1, measured after the timed region): `decode` (vectors/s + its roofline), `mse` of
 encode -> decode over the timed batches (AnyVectMSE, metrics.py:51-58), `beam1` (greedy encode), `batch_1024` (encode at
-the reference's default batch, qinco_cfg.yaml:38).
+the reference's default batch, qinco_cfg.yaml:38), `split_f16` (the opt-in split-fp16 form of the FFN blocks on the same
+batches: vectors/s, the code rows that differ from the fp32 path's, MSE; never the headline `value`).
 cpu_baseline: the oracle restatement with its codeword MLP on torch CPU ops (oracle/qinco_oracle.py, backend "torch":
 same op sequence as the reference's CPU path, codes equal to the numpy oracle and to the imported reference) timed on
 this box's host cores at the reference's batch of 1024 on a bounded sample.
@@ -45,6 +46,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+PEAK_F16_MFMA_TFLOPS = 2516.6   # dense fp16 / bf16 MFMA peak at 2.4 GHz (16 x the fp32-in rate; MI355X_MICROARCH.md)
 # measured in the build container (8 cores, C2, 256 vectors): imported reference wrapper 46.5 vec/s,
 # this port (torch backend) 42.3 vec/s, numpy oracle 9.3 vec/s -- all three give identical codes
 REF_OVER_PORT_CONTAINER = 1.10
@@ -318,6 +320,42 @@ def main():
                 out["beam1"] = {"value": timed_encode(batches[W:W + min(K, 2)]), "unit": "vectors/s", "A": eng.A, "B": 1,
                                 "gflop_per_vector": eng.flops_per_vector("encode") / 1e9}
                 eng.set_beam(B=cfg.B)
+            # ---- the opt-in split-fp16 form of the FFN blocks (include/qinco_hip.h QINCO_CREATE_SPLIT_F16): NOT the headline --
+            # `value` above is the fp32 path; this leg re-encodes the same timed batches and counts the code rows that change
+            try:
+                eng2 = QincoEngine(cfg, sd, max_batch=args.batch, split_f16=True)
+            except NotImplementedError:
+                eng2 = None
+            if eng2 is not None:
+                eng2.encode(batches[0], code_dtype=np.uint8)
+                torch.cuda.synchronize(dev)
+                eng2.profile_enable(True)
+                eng2.profile_read()
+                t3 = time.perf_counter()
+                codes2 = torch.stack([eng2.encode(batches[W + s], code_dtype=np.uint8) for s in range(K)])
+                torch.cuda.synchronize(dev)
+                dt2 = time.perf_counter() - t3
+                pr2 = eng2.profile_read()
+                eng2.profile_enable(False)
+                _, s_ms, s_fpl, s_ach = mlp_roofline(pr2)
+                differ = int((codes2.reshape(-1, cfg.M_total) != codes_all).any(dim=1).sum().item())
+                dec2 = eng2.decode(codes2.reshape(-1, cfg.M_total), check=False)
+                xs = torch.cat(batches[W:W + K])
+                blocks = 4.0 * cfg.L * cfg.De * cfg.dh - 2.0 * cfg.De * cfg.dh          # per row, block 0's up-projection folded
+                f16_tflops = 3.0 * blocks * (s_fpl / mlp_row) / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
+                out["split_f16"] = {
+                    "value": K * args.batch / dt2, "unit": "vectors/s", "ms_per_step": dt2 / K * 1e3,
+                    "speedup_vs_f32_path": (K * args.batch / dt2) / value if value > 0 else None,
+                    "rows_differing_from_f32_path": differ, "rows": int(codes_all.shape[0]),
+                    "mse": sqerr_sum(xs, dec2) / xs.shape[0],
+                    "roofline": {"bound": "mfma", "kernel": "qinco::mlp_split_kernel (+ xproj)", "avg_launch_ms": s_ms,
+                                 "achieved_algorithmic_fp32_equivalent_tflops": s_ach,
+                                 "f16_mfma_tflops_executed": f16_tflops, "peak_f16_mfma_tflops": PEAK_F16_MFMA_TFLOPS,
+                                 "frac_of_f16_peak": f16_tflops / PEAK_F16_MFMA_TFLOPS},
+                    "arithmetic": "FFN blocks: fp32 operands as fp16 hi + lo, 3 fp16 MFMAs per product, fp32 accumulate; rest fp32",
+                    "note": "opt-in (QincoEngine(split_f16=True) / qinco_create_ex); parity tests: tests/test_hip_parity.py::test_split_f16_*"}
+                del dec2, xs, codes2
+                eng2.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

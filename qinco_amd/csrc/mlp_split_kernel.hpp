@@ -145,10 +145,12 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
       __builtin_amdgcn_s_barrier();
     }
   };
-  auto ring_piece = [&]<int T, int q>(f32x4& dst) QINCO_LAMBDA {
+  auto ring_dma = [&]<int T, int q>() QINCO_LAMBDA {
     if constexpr (T % G == 0 && q < PER)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (T + P - G + q) * 64),
                                        (__attribute__((address_space(3))) void*)(wdst + ((T + P - G + q) % P) * 64), 16, 0, 0);
+  };
+  auto ring_read = [&]<int T, int q>(f32x4& dst) QINCO_LAMBDA {
     constexpr int slot = (T + q) % P;
     if constexpr (slot < 48) lds_read128<slot * 1024>(dst, ring_addr); else lds_read128<(slot - 48) * 1024>(dst, ring_addr_hi);
   };
@@ -221,16 +223,22 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   auto noop = []() QINCO_LAMBDA {};
   auto step = [&]<int TN>(f32x16& t0, f32x16& t1, const f16x8& bh, const f16x8& bl, auto&& extra) QINCO_LAMBDA {
 #define QINCO_SB __builtin_amdgcn_sched_barrier(0)
+    // (the reads go first: the last one has four MFMAs = 128 cycles to land before the wait; with one read per gap the last had
+    // 32 and every step stalled on it)
     t0 = QINCO_MFMA_H(as16(cur[0]), bh, t0);  QINCO_SB;
     ring_sync.template operator()<TN>();      QINCO_SB;
     t1 = QINCO_MFMA_H(as16(cur[2]), bh, t1);  QINCO_SB;
-    ring_piece.template operator()<TN, 0>(nxt[0]);  QINCO_SB;
+    ring_read.template operator()<TN, 0>(nxt[0]);
+    ring_read.template operator()<TN, 1>(nxt[1]);  QINCO_SB;
     t0 = QINCO_MFMA_H(as16(cur[0]), bl, t0);  QINCO_SB;
-    ring_piece.template operator()<TN, 1>(nxt[1]);  QINCO_SB;
+    ring_read.template operator()<TN, 2>(nxt[2]);
+    ring_read.template operator()<TN, 3>(nxt[3]);  QINCO_SB;
     t1 = QINCO_MFMA_H(as16(cur[2]), bl, t1);  QINCO_SB;
-    ring_piece.template operator()<TN, 2>(nxt[2]);  QINCO_SB;
+    ring_dma.template operator()<TN, 0>();
+    ring_dma.template operator()<TN, 1>();    QINCO_SB;
     t0 = QINCO_MFMA_H(as16(cur[1]), bh, t0);  QINCO_SB;
-    ring_piece.template operator()<TN, 3>(nxt[3]);  QINCO_SB;
+    ring_dma.template operator()<TN, 2>();
+    ring_dma.template operator()<TN, 3>();    QINCO_SB;
     t1 = QINCO_MFMA_H(as16(cur[3]), bh, t1);
     extra();
     QINCO_SB;

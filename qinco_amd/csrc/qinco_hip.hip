@@ -553,7 +553,7 @@ extern "C" int qinco_create_ex(const qinco_desc* desc, const qinco_weights* w, i
   if ((create_flags & QINCO_CREATE_SPLIT_F16) && d.M > 1) {
     // the split-fp16 instance of the shape (VAR bit 512); it peels FFN block 0 like FOLD2, so the model needs L >= 1
     const MlpInstance* sp = nullptr;
-    for (int pp : {96, 48})
+    for (int pp : {96, 64, 48})
       if (!sp) {
         const MlpInstance* c = find_mlp_instance(d.D, d.De, d.Dh, pp, 512 | 124);
         if (c && c->P == pp && c->var == (512 | 124)) sp = c;

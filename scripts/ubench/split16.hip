@@ -192,6 +192,11 @@ int main() {
   const int iters = 2000;
   const long nfrag = (long)(iters + 16) * 48 + 4 * P;
   f32x4* w; CK(hipMalloc(&w, nfrag * 1024)); CK(hipMemset(w, 0, nfrag * 1024));
+  if (getenv("SPLIT16_RANDOM")) {   // random fp16 weights (|w| < 2): the matrix pipe's power draw depends on the operand bits
+    std::vector<_Float16> hw((size_t)nfrag * 512);
+    for (auto& v : hw) v = (_Float16)(rnd() * 2.0f);
+    CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+  }
   float* out; CK(hipMalloc(&out, 256 * 256 * 4));
   long long* cyc; CK(hipMalloc(&cyc, 256 * 8));
   run_rate<0, 4>("mfma_only", w, out, cyc, iters);

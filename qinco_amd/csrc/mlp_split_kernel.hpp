@@ -71,12 +71,20 @@ QINCO_INL void lds_arrived4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
+// out_proj (D x De) takes the split form when it exists and has an even number of output blocks (host packer and kernel)
+constexpr bool split_out_proj(int D, int DE) { return D != DE && (D / 32) % 2 == 0; }
+// output blocks per out_proj pass: they accumulate in y's registers
+constexpr int split_out_group(int D, int DH) { return D / 32 < DH / 32 ? D / 32 : DH / 32; }
+
 template <int D, int DE, int DH, int P>
 __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   constexpr StreamDims SL = stream_dims(D, DE, DH, P, true, true);
   constexpr int NDB = SL.NDB, NEB = SL.NEB, NHB = SL.NHB;
   constexpr bool PROJ = SL.PROJ;
   constexpr int NZV = NEB > 8 ? 8 : NEB, NPARK = NEB - NZV;   // z blocks in registers / parked in LDS
+  constexpr bool SPLIT_OUT = split_out_proj(D, DE);            // out_proj in the split form (the host packs accordingly)
+  constexpr int OG = NDB < NHB ? NDB : NHB;                    // ... OG output blocks per pass
+  static_assert(!SPLIT_OUT || (NDB % OG == 0 && OG % 2 == 0), "out_proj passes");
   constexpr int G = 16, NG = P / G, PER = G / 4;   // ring group (barrier / refill cadence), groups in the ring, DMAs per wave
   constexpr int T_UPS = round_up(NHB * NEB * 4, P), T_DOWNS = round_up(NEB * NHB * 4, P);
   static_assert(P % G == 0 && NG >= 4, "ring: at least 4 groups of 16 fragments");
@@ -320,37 +328,22 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   }
 
   stamp(3);   // FFN blocks done
-  // ---- tail (fp32, as mlp_kernel.hpp E): out_proj + epilogue: cand = (out + coeff*c) + xhat ; dist = |x|^2 + |cand|^2 - 2 x.cand
+  // ---- tail: out_proj + epilogue: cand = (out + coeff*c) + xhat ; dist = |x|^2 + |cand|^2 - 2 x.cand  (mlp_kernel.hpp E) ----
   const long n = g / a.F;
   const float* xptr = a.x ? a.x + n * D + half * 4 : nullptr;
   float* outp = a.cand_out + row * D + half * 4;
   float s2 = 0.f, sx = 0.f, xn = 0.f;
-  static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
+  struct Epi {
     f32x16 cblk, xhb, xb;
-    if (a.add_c) cblk = load_block(cptr + ob * 32);
-    xhb = load_block(xhptr + ob * 32);
-    if (xptr) xb = load_block(xptr + ob * 32);
-    f32x16 o;
-    if constexpr (PROJ) {
-      o = zero16();
-      static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
-        constexpr int T = (ob * NEB + ib) * 4;     // fragments q = 0..3 of block pair (ob, ib): fp32 A operands, 4 MFMAs each
-        const f32x16 zb = zget.template operator()<ib>();
-        ldquad.template operator()<T + 4>(nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<4>([&]<int q>() QINCO_LAMBDA {
-          static_for<4>([&]<int e>() QINCO_LAMBDA { o = QINCO_MFMA(cur[q][e], zb[4 * q + e], o); });
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
-        static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
-      });
-      o = o * zsi;
-    } else {
-      o = zget.template operator()<ob>() * zsi;
-    }
-    if (a.add_c) o = o + cblk;
-    o = o + xhb;
+  };
+  auto load_epi = [&]<int ob>(Epi& e) QINCO_LAMBDA {
+    if (a.add_c) e.cblk = load_block(cptr + ob * 32);
+    e.xhb = load_block(xhptr + ob * 32);
+    if (xptr) e.xb = load_block(xptr + ob * 32);
+  };
+  auto epilogue = [&]<int ob>(f32x16 o, const Epi& e) QINCO_LAMBDA {
+    if (a.add_c) o = o + e.cblk;
+    o = o + e.xhb;
     if (valid) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -362,11 +355,62 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         s2 = fmaf(o[i], o[i], s2);
-        sx = fmaf(o[i], xb[i], sx);
-        xn = fmaf(xb[i], xb[i], xn);
+        sx = fmaf(o[i], e.xb[i], sx);
+        xn = fmaf(e.xb[i], e.xb[i], xn);
       }
     }
-  });
+  };
+  if constexpr (SPLIT_OUT) {
+    // out_proj in the split form too (it is 5 % of the MFMA cycles at D = 128 but 26 % at D = 768 once the blocks run on the fp16
+    // pipe): K-outer like the up-projection, OG output blocks per pass in y's registers, epilogue operands one block ahead.
+    const float mout = a.smul[2 + 2 * a.L];
+    static_for<NDB / OG>([&]<int ps>() QINCO_LAMBDA {
+      static_for<OG>([&]<int ob>() QINCO_LAMBDA { y[ob] = zero16(); });
+      SplitBlock sb[2];
+      sb[0] = split_block(zget.template operator()<0>());
+      static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
+        static_for<2>([&]<int c>() QINCO_LAMBDA {
+          static_for<OG / 2>([&]<int op>() QINCO_LAMBDA {
+            constexpr int T = ps * NEB * OG * 4 + ((ib * 2 + c) * (OG / 2) + op) * 4;
+            step.template operator()<T + 4>(y[2 * op], y[2 * op + 1], sb[ib & 1].h[c], sb[ib & 1].l[c], [&]() QINCO_LAMBDA {
+              if constexpr (c == 0 && op == 0 && ib + 1 < NEB) sb[(ib + 1) & 1] = split_block(zget.template operator()<ib + 1>());
+            });
+          });
+        });
+      });
+      Epi e[2];
+      load_epi.template operator()<ps * OG>(e[0]);
+      static_for<OG>([&]<int ob>() QINCO_LAMBDA {
+        if constexpr (ob + 1 < OG) load_epi.template operator()<ps * OG + ob + 1>(e[(ob + 1) & 1]);
+        epilogue.template operator()<ps * OG + ob>(y[ob] * mout, e[ob & 1]);
+      });
+    });
+  } else {
+    static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
+      Epi e;
+      load_epi.template operator()<ob>(e);
+      f32x16 o;
+      if constexpr (PROJ) {   // fp32 (odd number of output blocks: D = 96, the 32-d test models)
+        o = zero16();
+        static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
+          constexpr int T = (ob * NEB + ib) * 4;     // fragments q = 0..3 of block pair (ob, ib): fp32 A operands, 4 MFMAs each
+          const f32x16 zb = zget.template operator()<ib>();
+          ldquad.template operator()<T + 4>(nxt);
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<4>([&]<int q>() QINCO_LAMBDA {
+            static_for<4>([&]<int e4>() QINCO_LAMBDA { o = QINCO_MFMA(cur[q][e4], zb[4 * q + e4], o); });
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
+          static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
+        });
+        o = o * zsi;
+      } else {
+        o = zget.template operator()<ob>() * zsi;
+      }
+      epilogue.template operator()<ob>(o, e);
+    });
+  }
   if (a.dist_out) {
     s2 += __shfl_xor(s2, 32);
     sx += __shfl_xor(sx, 32);

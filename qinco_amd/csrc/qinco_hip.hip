@@ -270,13 +270,17 @@ static void put_split_frags(std::vector<float>& s, const float* W, int I, int o,
     }
 }
 
-// up-projection (Dh x De), hidden half hh of nhs: K-outer -- for ib: for c: for each pair of hidden blocks: hi, lo, hi, lo
+// K-outer sections (up-projection Dh x De; out_proj D x De in passes of `no` output blocks): for ib: for c: for each output
+// block of [o0, o0 + no): hi, lo
+static void pack_split_kouter(std::vector<float>& s, const float* W, int I, int o0, int no, float scale) {
+  for (int ib = 0; ib < I / 32; ++ib)
+    for (int c = 0; c < 2; ++c)
+      for (int o = 0; o < no; ++o) put_split_frags(s, W, I, o0 + o, ib, c, scale);
+}
 static void pack_split_up(std::vector<float>& s, const float* W, int O, int I, int hh, int nhs, float scale, int T) {
   size_t start = s.size();
   const int noh = O / 32 / nhs;
-  for (int ib = 0; ib < I / 32; ++ib)
-    for (int c = 0; c < 2; ++c)
-      for (int o = 0; o < noh; ++o) put_split_frags(s, W, I, hh * noh + o, ib, c, scale);
+  pack_split_kouter(s, W, I, hh * noh, noh, scale);
   pad_to(s, start, T);
 }
 
@@ -703,9 +707,18 @@ extern "C" int qinco_create_ex(const qinco_desc* desc, const qinco_weights* w, i
       if (!(h->fold2 && l == 0)) pack_obouter(s, up, d.Dh, d.De, sd.T_UP);
       pack_obouter(s, dn, d.De, d.Dh, sd.T_DOWN);
     }
-    if (h->split16 && (rc = upload(h, &h->smul[m], smul.data(), smul.size()))) return bail(rc);
-    if (sd.PROJ && !tile16) pack_obouter(s, w->out_proj[m], d.D, d.De, sd.T_OUT);
+    if (h->split16 && sd.PROJ && (d.D / 32) % 2 == 0) {   // = split_out_proj(D, De): out_proj in the split form, K-outer passes
+      const float so = split_weight_scale(w->out_proj[m], (size_t)d.D * d.De);
+      const int og = d.D / 32 < d.Dh / 32 ? d.D / 32 : d.Dh / 32;   // = split_out_group(D, Dh)
+      const size_t start = s.size();
+      for (int o0 = 0; o0 < d.D / 32; o0 += og) pack_split_kouter(s, w->out_proj[m], d.De, o0, og, so);
+      pad_to(s, start, sd.T_OUT);
+      smul.push_back(1.f / (smul[0] * so));   // o = m_out acc,  acc = W_out' z' = 2^(c+s) W_out z
+    } else if (sd.PROJ && !tile16) {
+      pack_obouter(s, w->out_proj[m], d.D, d.De, sd.T_OUT);
+    }
     if ((long)(s.size() / 256) != sd.total(d.L)) return bail(fail(QINCO_ERR_INVALID, "internal: stream size mismatch"));
+    if (h->split16 && (rc = upload(h, &h->smul[m], smul.data(), smul.size()))) return bail(rc);
     s.resize(s.size() + (size_t)kRing * 256, 0.f);  // the ring prefetches P fragments past the end
     float* ds = nullptr;
     if ((rc = upload(h, &ds, s.data(), s.size()))) return bail(rc);

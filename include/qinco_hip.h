@@ -87,7 +87,9 @@ QINCO_API int qinco_create(const qinco_desc* desc, const qinco_weights* weights,
  * FLOPs of qinco2-L) on the fp16 matrix pipe with every fp32 operand split into two fp16 values (hi + lo, three MFMAs per
  * product, fp32 accumulation; csrc/mlp_split_kernel.hpp) instead of the fp32-in MFMA, which runs at 1/16 of the fp16 rate on
  * gfx950.  Same function and an error of the same class as the fp32 path against a float64 evaluation, but not the
- * same bits: opt-in, off by default; QINCO_ERR_UNSUPPORTED if the shape has no split instance (csrc/shapes.def) or L == 0. */
+ * same bits: opt-in, off by default; QINCO_ERR_UNSUPPORTED if the shape has no split instance (csrc/shapes.def) or L == 0.
+ * fp16 has a range: activations beyond |z| ~ 8000 (never seen with std-normalised data) overflow; the kernel then raises the
+ * sticky device flag and qinco_encode_host / qinco_check return QINCO_ERR_RANGE instead of codes selected from NaNs. */
 enum { QINCO_CREATE_SPLIT_F16 = 1 };
 QINCO_API int qinco_create_ex(const qinco_desc* desc, const qinco_weights* weights, int32_t create_flags, qinco_handle* out);
 QINCO_API int qinco_destroy(qinco_handle h);

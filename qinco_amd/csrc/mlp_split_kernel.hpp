@@ -416,6 +416,9 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
     sx += __shfl_xor(sx, 32);
     xn += __shfl_xor(xn, 32);
     if (valid && half == 0) a.dist_out[row] = (xn + s2) - 2.f * sx;
+    // an fp32 value beyond the fp16 range (|z'| > 65504) became inf in the split and NaN in the products: say so instead of
+    // letting the selection sort a NaN (qinco_check / the host entry points report it; the fp32 path has no such limit)
+    if (a.err && !(s2 < 3.0e38f)) *a.err = 2;
   }
   stamp(4);
   // no LDS-DMA may be in flight when the wave ends (its LDS could be handed to the next workgroup)

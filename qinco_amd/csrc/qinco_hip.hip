@@ -819,6 +819,7 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
     a.ttab = h->ttab[m];
   }
   a.smul = h->split16 ? h->smul[m] : nullptr;
+  a.err = h->split16 ? h->err_flag : nullptr;
 #ifdef QINCO_TIMELINE
   {
     const size_t tiles = (size_t)((a.R + 31) / 32 + 4);
@@ -1122,6 +1123,8 @@ static int ensure_stage(void** p, size_t* cap, size_t need) {
   return 0;
 }
 
+static int check_decode_range(qinco_handle_s* h);
+
 extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int64_t stride, int64_t n, void* codes_out,
                                  int code_dtype, float* xhat_out, int flags) {
   int rc = check_common(h, x, codes_out, n, code_dtype, "qinco_encode_host");
@@ -1153,7 +1156,7 @@ extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int
     if (xhat_out)
       HIP_TRY(hipMemcpy(xhat_out + (size_t)i0 * h->d.D, h->stage_out, (size_t)nb * h->d.D * 4, hipMemcpyDeviceToHost));
   }
-  return QINCO_OK;
+  return h->split16 ? check_decode_range(h) : QINCO_OK;   // (the split form's overflow flag; the copies above have synchronised)
 }
 
 // The range flag is sticky on the device: import_codes_kernel raises it (and decodes the offending code as 0), the
@@ -1163,6 +1166,9 @@ static int check_decode_range(qinco_handle_s* h) {
   HIP_TRY(hipMemcpy(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost));
   if (flag) {
     HIP_TRY(hipMemset(h->err_flag, 0, sizeof(int)));
+    if (flag == 2)
+      return fail(QINCO_ERR_RANGE, "split-fp16 form: an activation of the codeword MLP left the fp16 range (or the input is not finite); "
+                                   "create the handle without QINCO_CREATE_SPLIT_F16 for this model / data");
     return fail(QINCO_ERR_RANGE, "qinco_decode: a code is outside [0, K)");
   }
   return 0;

@@ -122,7 +122,6 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
                                        (__attribute__((address_space(3))) void*)(wdst + ((T0 + q) % P) * 64), 16, 0, 0);
     });
   };
-  static_for<NG - 1>([&]<int i>() QINCO_LAMBDA { dma_group.template operator()<i * G>(); });
   const unsigned ring_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds_ring + lane * 16;
   const unsigned ring_addr_hi = ring_addr + 48 * 1024;   // (the offset field of a DS instruction is 16 bits)
   // Quad T .. T+3 of the current section -> dst.  At a group boundary: every LDS read this wave has issued -- the previous
@@ -197,24 +196,80 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
     }
   };
 
-  // ---- head: z' = 2^c (T[cid] + U[group]) ------------------------------------------------------------------
+  // ---- head: z' = 2^c (T[cid] + U[group]);  FFN block 0's hidden layer is folded: h = relu(P[cid] + Q[group]),
+  //      y = split(2^a h).
+  // The table rows T[cid], P[cid] are 32 different rows per wave.  Gathered lane by lane in the C/D layout (16 B per lane, 32
+  // rows per instruction) they cost the texture addresser ~64 cycles per instruction, shared by the CU's four waves: 96
+  // instructions = 24 k cycles at the qinco2-S shape, 36 % of its tile, however many are in flight (measured: batching the
+  // loads changed nothing).  So the rows are fetched COALESCED -- a slice of 2 blocks = 256 B of a row per 16 lanes, four rows
+  // per instruction -- and transposed through LDS: this wave's quarter of the weight ring, which is idle until the head is
+  // done (the ring prologue starts behind it).  The per-group rows U[g], Q[g] are fetched in the same lane mapping (their
+  // duplicates within a load coalesce) and added before the transpose. ----
   f32x16 y[NHB];     // up-projection accumulators, then (bit pattern of) SplitBlock
   {
-    const float* tptr = a.ttab + (long)cid * DE + half * 4;
-    const float* uptr = a.uproj + g * DE + half * 4;
-    static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-      zset.template operator()<ob>((load_block(tptr + ob * 32) + load_block(uptr + ob * 32)) * zs);
-    });
-    // FFN block 0's hidden layer is folded: h = relu(P[cid] + Q[group]); y = split(2^a h)
-    const float* pptr = a.ptab + (long)cid * DH + half * 4;
-    const float* qptr = a.qproj + g * DH + half * 4;
+    constexpr int RSQ = 17;                          // staging row stride in float4 (272 B: rows shift by 4 banks)
+    static_assert(32 * RSQ <= P * 16, "the staging buffer is a quarter of the ring");
+    f32x4* stage = lds_ring + wave_u * (P * 16);
     const float m0 = a.smul[2];
-    static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
-      f32x16 v = load_block(pptr + ob * 32) + load_block(qptr + ob * 32);
-      relu16(v);
-      y[ob] = __builtin_bit_cast(f32x16, split_block(v * m0));
-      pin_a(y[ob]);
+    int rc[8], rg[8];                                // codeword / group of the row that this lane's 16-lane group fetches in load i
+    static_for<8>([&]<int i>() QINCO_LAMBDA {
+      rc[i] = __shfl(cid, 4 * i + (lane >> 4));
+      rg[i] = __shfl((int)g, 4 * i + (lane >> 4));     // (groups = rows / A < 2^31)
     });
+    constexpr int NSZ = NEB / 2, NS = NSZ + NHB / 2;   // slices of T, then of P
+    struct Slice {
+      f32x4 r[8], u[8];   // 8 + 8 coalesced loads: table / per-group rows 4i + (lane >> 4), float4 (lane & 15) of the slice
+    };
+    constexpr int AHEAD = 1;   // slices in flight beyond the current one (64 registers each)
+    Slice sl[AHEAD + 1];
+    auto fetch = [&]<int S>(Slice& d) QINCO_LAMBDA {
+      constexpr bool Z = S < NSZ;
+      constexpr int s = Z ? S : S - NSZ;
+      const float* tab = Z ? a.ttab : a.ptab;
+      const float* grp = Z ? a.uproj : a.qproj;
+      constexpr int stride = Z ? DE : DH;
+      static_for<8>([&]<int i>() QINCO_LAMBDA {
+        d.r[i] = *reinterpret_cast<const f32x4*>(tab + (long)rc[i] * stride + s * 64 + (lane & 15) * 4);
+      });
+      static_for<8>([&]<int i>() QINCO_LAMBDA {
+        d.u[i] = *reinterpret_cast<const f32x4*>(grp + (long)rg[i] * stride + s * 64 + (lane & 15) * 4);
+      });
+    };
+    auto staged_block = [&]<int b>() QINCO_LAMBDA -> f32x16 {
+      f32x16 v;
+      static_for<4>([&]<int q>() QINCO_LAMBDA {
+        const f32x4 t = stage[j * RSQ + b * 8 + 2 * q + half];
+        static_for<4>([&]<int e>() QINCO_LAMBDA { v[4 * q + e] = t[e]; });
+      });
+      return v;
+    };
+    static_for<AHEAD>([&]<int S>() QINCO_LAMBDA {
+      if constexpr (S < NS) fetch.template operator()<S>(sl[S % (AHEAD + 1)]);
+    });
+    static_for<NS>([&]<int S>() QINCO_LAMBDA {
+      if constexpr (S + AHEAD < NS) fetch.template operator()<S + AHEAD>(sl[(S + AHEAD) % (AHEAD + 1)]);
+      Slice& c = sl[S % (AHEAD + 1)];
+      static_for<8>([&]<int i>() QINCO_LAMBDA { stage[(4 * i + (lane >> 4)) * RSQ + (lane & 15)] = c.r[i] + c.u[i]; });
+      const f32x16 v0 = staged_block.template operator()<0>();
+      const f32x16 v1 = staged_block.template operator()<1>();
+      if constexpr (S < NSZ) {
+        zset.template operator()<2 * S>(v0 * zs);
+        zset.template operator()<2 * S + 1>(v1 * zs);
+      } else {
+        constexpr int ob = 2 * (S - NSZ);
+        f32x16 w0 = v0, w1 = v1;
+        relu16(w0);
+        relu16(w1);
+        y[ob] = __builtin_bit_cast(f32x16, split_block(w0 * m0));
+        y[ob + 1] = __builtin_bit_cast(f32x16, split_block(w1 * m0));
+        pin_a(y[ob]);
+        pin_a(y[ob + 1]);
+      }
+    });
+    // every wave is done with its staging buffer before anybody's DMA lands in the ring
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    static_for<NG - 1>([&]<int i>() QINCO_LAMBDA { dma_group.template operator()<i * G>(); });
   }
 
   f32x4 cur[4], nxt[4];
@@ -228,7 +283,6 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   // plus `extra`: VALU work of a neighbouring stage that the MFMAs do not depend on; then the next quad must have arrived.
   // Everything is pinned by scheduling barriers: left alone, hipcc hoists the MFMAs above the reads (the wait then exposes
   // the LDS latency in every step), and a wave that issues its four reads and four DMAs in one go leaves the pipe idle.
-  auto noop = []() QINCO_LAMBDA {};
   auto step = [&]<int TN>(f32x16& t0, f32x16& t1, const f16x8& bh, const f16x8& bl, auto&& extra) QINCO_LAMBDA {
 #define QINCO_SB __builtin_amdgcn_sched_barrier(0)
     // (the reads go first: the last one has four MFMAs = 128 cycles to land before the wait; with one read per gap the last had
@@ -341,6 +395,7 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
     e.xhb = load_block(xhptr + ob * 32);
     if (xptr) e.xb = load_block(xptr + ob * 32);
   };
+  constexpr int NPRE = NDB <= 4 ? NDB : (SPLIT_OUT && OG <= 4 ? OG : 0);   // blocks whose operands are fetched together
   auto epilogue = [&]<int ob>(f32x16 o, const Epi& e) QINCO_LAMBDA {
     if (a.add_c) o = o + e.cblk;
     o = o + e.xhb;
@@ -378,17 +433,25 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
           });
         });
       });
-      Epi e[2];
-      load_epi.template operator()<ps * OG>(e[0]);
-      static_for<OG>([&]<int ob>() QINCO_LAMBDA {
-        if constexpr (ob + 1 < OG) load_epi.template operator()<ps * OG + ob + 1>(e[(ob + 1) & 1]);
-        epilogue.template operator()<ps * OG + ob>(y[ob] * mout, e[ob & 1]);
-      });
+      if constexpr (NPRE > 0) {
+        Epi e[OG];
+        static_for<OG>([&]<int ob>() QINCO_LAMBDA { load_epi.template operator()<ps * OG + ob>(e[ob]); });
+        static_for<OG>([&]<int ob>() QINCO_LAMBDA { epilogue.template operator()<ps * OG + ob>(y[ob] * mout, e[ob]); });
+      } else {
+        Epi e[2];
+        load_epi.template operator()<ps * OG>(e[0]);
+        static_for<OG>([&]<int ob>() QINCO_LAMBDA {
+          if constexpr (ob + 1 < OG) load_epi.template operator()<ps * OG + ob + 1>(e[(ob + 1) & 1]);
+          epilogue.template operator()<ps * OG + ob>(y[ob] * mout, e[ob & 1]);
+        });
+      }
     });
   } else {
+    Epi ep[NPRE > 0 ? NPRE : 1];
+    if constexpr (NPRE > 0) static_for<NPRE>([&]<int ob>() QINCO_LAMBDA { load_epi.template operator()<ob>(ep[ob]); });
     static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
       Epi e;
-      load_epi.template operator()<ob>(e);
+      if constexpr (NPRE > 0) e = ep[ob]; else load_epi.template operator()<ob>(e);
       f32x16 o;
       if constexpr (PROJ) {   // fp32 (odd number of output blocks: D = 96, the 32-d test models)
         o = zero16();

@@ -343,8 +343,10 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
           constexpr int T = ((og * NHB + ib) * 2 + c) * 4;
           const SplitBlock s = __builtin_bit_cast(SplitBlock, y[ib]);
           step.template operator()<T + 4>(t[og & 1][0], t[og & 1][1], s.h[c], s.l[c], [&]() QINCO_LAMBDA {
-            if constexpr (LAZY && og == 0 && c == 0 && ib + 1 < NHB) convert_y.template operator()<ib + 1>(mup);
-            if constexpr (og > 0 && ib == 0 && c == 0) residual.template operator()<og - 1>();
+            constexpr int nb = ib + 1 < NHB ? ib + 1 : 0;
+            if constexpr (LAZY && og == 0 && c == 0 && ib + 1 < NHB) convert_y.template operator()<nb>(mup);
+            constexpr int pg = og > 0 ? og - 1 : 0;
+            if constexpr (og > 0 && ib == 0 && c == 0) residual.template operator()<pg>();
           });
         });
       });
@@ -363,7 +365,8 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
         static_for<NHB / 2>([&]<int op>() QINCO_LAMBDA {
           constexpr int T = ((ib * 2 + c) * (NHB / 2) + op) * 4;
           step.template operator()<T + 4>(y[2 * op], y[2 * op + 1], sb[ib & 1].h[c], sb[ib & 1].l[c], [&]() QINCO_LAMBDA {
-            if constexpr (c == 0 && op == 0 && ib + 1 < NEB) sb[(ib + 1) & 1] = split_block(zget.template operator()<ib + 1>());
+            constexpr int nb = ib + 1 < NEB ? ib + 1 : 0;
+            if constexpr (c == 0 && op == 0 && ib + 1 < NEB) sb[nb & 1] = split_block(zget.template operator()<nb>());
           });
         });
       });
@@ -428,7 +431,8 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
           static_for<OG / 2>([&]<int op>() QINCO_LAMBDA {
             constexpr int T = ps * NEB * OG * 4 + ((ib * 2 + c) * (OG / 2) + op) * 4;
             step.template operator()<T + 4>(y[2 * op], y[2 * op + 1], sb[ib & 1].h[c], sb[ib & 1].l[c], [&]() QINCO_LAMBDA {
-              if constexpr (c == 0 && op == 0 && ib + 1 < NEB) sb[(ib + 1) & 1] = split_block(zget.template operator()<ib + 1>());
+              constexpr int nb = ib + 1 < NEB ? ib + 1 : 0;
+            if constexpr (c == 0 && op == 0 && ib + 1 < NEB) sb[nb & 1] = split_block(zget.template operator()<nb>());
             });
           });
         });

@@ -72,6 +72,7 @@ struct XprojArgs {
   long G;
   const f32x4* wq;        // FOLD2: W_up[0] (Dh x De) as fragments in (ob, ib, q) order, or nullptr
   float* qproj;           // FOLD2: (G, Dh)
+  const float* smul;      // split-fp16 form (xproj_split_kernel): [2^cx, 1/(2^cx s_u), 2^cu, 1/(2^cu s_q)]; wx = the whole stream
 };
 
 }  // namespace qinco

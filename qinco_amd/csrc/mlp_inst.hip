@@ -45,7 +45,12 @@ hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::Mlp
 
 extern "C" __attribute__((visibility("hidden")))
 hipError_t QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::XprojArgs* a, hipStream_t stream) {
-#if (QVAR & 128)
+#if (QVAR & 512)
+  if (a->G <= 0) return hipSuccess;
+  const unsigned grid = (unsigned)((a->G + 127) / 128);
+  hipLaunchKernelGGL((qinco::xproj_split_kernel<QD, QDE, QDH, QP>), dim3(grid), dim3(256), 0, stream, *a);
+  return hipGetLastError();
+#elif (QVAR & 128)
   (void)a;
   (void)stream;
   return hipErrorNotSupported;  // the 16-row form is never folded

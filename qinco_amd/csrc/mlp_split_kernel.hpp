@@ -493,4 +493,170 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   stamp(5);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// xproj in the split form: U[g] = W_cat[:, De:] . xhat_g and Q[g] = W_up[0] . U[g] for every (vector, beam) group, the
+// per-group half of the folded head (mlp_kernel.hpp xproj_kernel is the fp32 form: 5-14 % of a split-form encode).  Same tile
+// and ring protocol as mlp_split_kernel: a wave owns 32 groups, both GEMMs K-outer (all output chains advance together), xhat
+// blocks fetched and split one block ahead, U kept in registers between the two GEMMs; U and Q are stored as fp32.
+// Stream: [U section: for ib < D/32: for c: for o < De/32: hi, lo][Q section: for ib < De/32: for c: for o < Dh/32: hi, lo].
+// smul = [2^cx, 1 / (2^cx s_u), 2^cu, 1 / (2^cu s_q)].
+// ------------------------------------------------------------------------------------------------------------------------
+template <int P>
+struct SplitRing {   // the workgroup-shared LDS-DMA ring of mlp_split_kernel as an object (same protocol, same comments apply)
+  static constexpr int G = 16, NG = P / G, PER = G / 4;
+  const f32x4* wsrc;
+  f32x4* wdst;
+  unsigned addr, addr_hi;
+  QINCO_INL void init(const f32x4* stream, f32x4* lds, int lane, int wave_u) {
+    wsrc = stream + lane + wave_u * PER * 64;
+    wdst = lds + wave_u * PER * 64;
+    addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds + lane * 16;
+    addr_hi = addr + 48 * 1024;
+  }
+  template <int T0>
+  QINCO_INL void dma_group() {
+    static_for<PER>([&]<int q>() QINCO_LAMBDA { dma<T0 + G - P, q>(); });
+  }
+  template <int T, int q>   // the q-th DMA of the refill that belongs to the boundary in front of fragment T
+  QINCO_INL void dma() {
+    if constexpr (q < PER)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (T + P - G + q) * 64),
+                                       (__attribute__((address_space(3))) void*)(wdst + ((T + P - G + q) % P) * 64), 16, 0, 0);
+  }
+  QINCO_INL void prologue() {
+    static_for<NG - 1>([&]<int i>() QINCO_LAMBDA { dma_group<i * G>(); });
+  }
+  template <int T>
+  QINCO_INL void sync() {
+    if constexpr (T % G == 0) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0070 | (((NG - 2) * PER) & 15) | ((((NG - 2) * PER) >> 4) << 14));
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  template <int T, int q>
+  QINCO_INL void read(f32x4& dst) {
+    constexpr int slot = (T + q) % P;
+    if constexpr (slot < 48) lds_read128<slot * 1024>(dst, addr); else lds_read128<(slot - 48) * 1024>(dst, addr_hi);
+  }
+  template <int T>
+  QINCO_INL void ldquad(f32x4 (&dst)[4]) {
+    sync<T>();
+    if constexpr (T % G == 0) static_for<PER>([&]<int q>() QINCO_LAMBDA { dma<T, q>(); });
+    static_for<4>([&]<int q>() QINCO_LAMBDA { read<T, q>(dst[q]); });
+  }
+  // one step: the six MFMAs of quad `cur` with the ring traffic of the next quad (fragments TN ..) spread between them
+  template <int TN, class F>
+  QINCO_INL void step(f32x4 (&cur)[4], f32x4 (&nxt)[4], f32x16& t0, f32x16& t1, const f16x8& bh, const f16x8& bl, F&& extra) {
+#define QINCO_SB __builtin_amdgcn_sched_barrier(0)
+#define QINCO_H(v) __builtin_bit_cast(f16x8, v)
+    t0 = QINCO_MFMA_H(QINCO_H(cur[0]), bh, t0);  QINCO_SB;
+    sync<TN>();                                  QINCO_SB;
+    t1 = QINCO_MFMA_H(QINCO_H(cur[2]), bh, t1);  QINCO_SB;
+    read<TN, 0>(nxt[0]);
+    read<TN, 1>(nxt[1]);                         QINCO_SB;
+    t0 = QINCO_MFMA_H(QINCO_H(cur[0]), bl, t0);  QINCO_SB;
+    read<TN, 2>(nxt[2]);
+    read<TN, 3>(nxt[3]);                         QINCO_SB;
+    t1 = QINCO_MFMA_H(QINCO_H(cur[2]), bl, t1);  QINCO_SB;
+    if constexpr (TN % G == 0) { dma<TN, 0>(); dma<TN, 1>(); }
+    QINCO_SB;
+    t0 = QINCO_MFMA_H(QINCO_H(cur[1]), bh, t0);  QINCO_SB;
+    if constexpr (TN % G == 0) { dma<TN, 2>(); dma<TN, 3>(); }
+    QINCO_SB;
+    t1 = QINCO_MFMA_H(QINCO_H(cur[3]), bh, t1);
+    extra();
+    QINCO_SB;
+#undef QINCO_H
+#undef QINCO_SB
+    lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
+    static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
+  }
+  template <int FROM, int TO>   // the padding of a section, then the next section's origin
+  QINCO_INL void end_section(f32x4 (&cur)[4], f32x4 (&nxt)[4]) {
+    static_for<(TO - FROM) / 4>([&]<int i>() QINCO_LAMBDA {
+      ldquad<FROM + 4 * i + 4>(nxt);
+      lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
+      static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
+    });
+    wsrc += TO * 64;
+  }
+};
+
+template <int D, int DE, int DH, int P>
+__global__ void __launch_bounds__(256, 1) xproj_split_kernel(XprojArgs a) {
+  constexpr int NDB = D / 32, NEB = DE / 32, NHB = DH / 32;
+  constexpr int T_U = round_up(4 * NDB * NEB, P);   // (the Q section, round_up(4 NEB NHB, P) fragments, ends the stream)
+  static_assert(NEB % 2 == 0 && NHB % 2 == 0, "output blocks are processed in pairs");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int j = lane & 31, half = lane >> 5;
+  long g = ((long)blockIdx.x * 4 + wave) * 32 + j;   // every wave runs (barriers); groups past G are clamped, never stored
+  const bool valid = g < a.G;
+  if (!valid) g = a.G - 1;
+  const float* xp = a.xhat + g * D + half * 4;
+  const float xs = a.smul[0], mu = a.smul[1], us = a.smul[2], mq = a.smul[3];
+
+  __shared__ f32x4 lds_ring[P * 64];
+  SplitRing<P> ring;
+  ring.init(a.wx, lds_ring, lane, wave_u);
+  ring.prologue();
+  f32x4 cur[4], nxt[4];
+  SplitBlock sb[2];
+  sb[0] = split_block(load_block(xp) * xs);
+  ring.template ldquad<0>(cur);
+  lds_arrived4(cur[0], cur[1], cur[2], cur[3]);
+
+  auto store_block = [&](float* p, const f32x16& v) QINCO_LAMBDA {
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(p + 8 * q) = t;
+      }
+    }
+  };
+
+  // ---- U = W_cat[:, De:] . xhat ----
+  f32x16 u[NEB];
+  static_for<NEB>([&]<int ob>() QINCO_LAMBDA { u[ob] = zero16(); });
+  static_for<NDB>([&]<int ib>() QINCO_LAMBDA {
+    static_for<2>([&]<int c>() QINCO_LAMBDA {
+      static_for<NEB / 2>([&]<int op>() QINCO_LAMBDA {
+        constexpr int T = ((ib * 2 + c) * (NEB / 2) + op) * 4;
+        constexpr int nb = ib + 1 < NDB ? ib + 1 : 0;
+        ring.template step<T + 4>(cur, nxt, u[2 * op], u[2 * op + 1], sb[ib & 1].h[c], sb[ib & 1].l[c], [&]() QINCO_LAMBDA {
+          if constexpr (c == 0 && op == 0 && ib + 1 < NDB) sb[nb & 1] = split_block(load_block(xp + nb * 32) * xs);
+        });
+      });
+    });
+  });
+  ring.template end_section<4 * NDB * NEB, T_U>(cur, nxt);
+  float* up = a.uproj + g * DE + half * 4;
+  static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+    u[ob] = u[ob] * mu;
+    store_block(up + ob * 32, u[ob]);
+  });
+
+  // ---- Q = W_up[0] . U ----
+  f32x16 qa[NHB];
+  static_for<NHB>([&]<int ob>() QINCO_LAMBDA { qa[ob] = zero16(); });
+  sb[0] = split_block(u[0] * us);
+  static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
+    static_for<2>([&]<int c>() QINCO_LAMBDA {
+      static_for<NHB / 2>([&]<int op>() QINCO_LAMBDA {
+        constexpr int T = ((ib * 2 + c) * (NHB / 2) + op) * 4;
+        constexpr int nb = ib + 1 < NEB ? ib + 1 : 0;
+        ring.template step<T + 4>(cur, nxt, qa[2 * op], qa[2 * op + 1], sb[ib & 1].h[c], sb[ib & 1].l[c], [&]() QINCO_LAMBDA {
+          if constexpr (c == 0 && op == 0 && ib + 1 < NEB) sb[nb & 1] = split_block(u[nb] * us);
+        });
+      });
+    });
+  });
+  float* qp = a.qproj + g * DH + half * 4;
+  static_for<NHB>([&]<int ob>() QINCO_LAMBDA { store_block(qp + ob * 32, qa[ob] * mq); });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the wave ends
+}
+
 }  // namespace qinco

@@ -89,6 +89,7 @@ struct qinco_handle_s {
   std::vector<f32x4*> wstream;
   bool split16 = false;             // split-fp16 FFN blocks (QINCO_FLAG_SPLIT_F16; mlp_split_kernel.hpp)
   std::vector<float*> smul;         // per step: [2^c, 2^-c, m_up[0], m_down[0], m_up[1], ...]
+  std::vector<float*> xsmul;        // per step, xproj_split_kernel: [2^cx, 1/(2^cx s_u), 2^cu, 1/(2^cu s_q)]
   // decode runs one row per group: nothing to share, so the folded head only adds the xproj launch and the U / Q round trip
   // through HBM.  When the shape has an un-folded instance, decode uses it with its own (complete) weight stream.
   const MlpInstance* dec_inst = nullptr;
@@ -272,15 +273,15 @@ static void put_split_frags(std::vector<float>& s, const float* W, int I, int o,
 
 // K-outer sections (up-projection Dh x De; out_proj D x De in passes of `no` output blocks): for ib: for c: for each output
 // block of [o0, o0 + no): hi, lo
-static void pack_split_kouter(std::vector<float>& s, const float* W, int I, int o0, int no, float scale) {
-  for (int ib = 0; ib < I / 32; ++ib)
+static void pack_split_kouter(std::vector<float>& s, const float* W, int ld, int K, int o0, int no, float scale) {
+  for (int ib = 0; ib < K / 32; ++ib)   // (ld = row stride of W, K = its input features: W may be a column block of a wider matrix)
     for (int c = 0; c < 2; ++c)
-      for (int o = 0; o < no; ++o) put_split_frags(s, W, I, o0 + o, ib, c, scale);
+      for (int o = 0; o < no; ++o) put_split_frags(s, W, ld, o0 + o, ib, c, scale);
 }
 static void pack_split_up(std::vector<float>& s, const float* W, int O, int I, int hh, int nhs, float scale, int T) {
   size_t start = s.size();
   const int noh = O / 32 / nhs;
-  pack_split_kouter(s, W, I, hh * noh, noh, scale);
+  pack_split_kouter(s, W, I, I, hh * noh, noh, scale);
   pad_to(s, start, T);
 }
 
@@ -297,9 +298,9 @@ static void pack_split_down(std::vector<float>& s, const float* W, int O, int I,
 
 // 2^e with max |scale * W| in [512, 1024): every weight down to 2^-11 of the largest keeps a normal fp16 lo part (>= 2^-14)
 // and nothing comes near the fp16 maximum (65504).
-static float split_weight_scale(const float* W, size_t n) {
-  float mx = 0.f;
-  for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(W[i]));
+static float split_weight_scale(const float* W, size_t n, size_t cols = 0, size_t ld = 0) {
+  float mx = 0.f;   // (cols / ld given: the first `cols` columns of rows that are `ld` apart; n = rows * cols)
+  for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(cols ? W[(i / cols) * ld + i % cols] : W[i]));
   if (!(mx > 0.f) || !std::isfinite(mx)) return 1.f;
   return ldexpf(1.f, 9 - ilogbf(mx));
 }
@@ -470,6 +471,27 @@ static int build_fold_tables(qinco_handle_s* h, const qinco_weights* w, int m) {
   float* ds = nullptr;
   if ((rc = upload(h, &ds, s.data(), s.size()))) return rc;
   h->wx_stream[m] = reinterpret_cast<f32x4*>(ds);
+  if (h->split16) {   // xproj_split_kernel: one stream [U section][Q section] of fp16 hi / lo fragments + its scalings
+    const int Dh = d.Dh, P = h->inst->P;
+    const float* up0 = w->up[(size_t)m * d.L];
+    if (!up0) return fail(QINCO_ERR_INVALID, "qinco_create: FFN weights[%d][0] null", m);
+    const float su = split_weight_scale(wc + De, (size_t)De * D, D, I), sq = split_weight_scale(up0, (size_t)Dh * De);
+    std::vector<float> xs;
+    size_t start = 0;
+    pack_split_kouter(xs, wc + De, I, D, 0, De / 32, su);
+    pad_to(xs, start, qinco::round_up(4 * (D / 32) * (De / 32), P));
+    start = xs.size();
+    pack_split_kouter(xs, up0, De, De, 0, Dh / 32, sq);
+    pad_to(xs, start, qinco::round_up(4 * (De / 32) * (Dh / 32), P));
+    xs.resize(xs.size() + (size_t)P * 256, 0.f);   // the ring prefetches P fragments past the end
+    float* dxs = nullptr;
+    if ((rc = upload(h, &dxs, xs.data(), xs.size()))) return rc;
+    dev_free(h, ds);                               // (the fp32 fragments of W_cat[:, De:] are not used in this mode)
+    h->wx_stream[m] = reinterpret_cast<f32x4*>(dxs);
+    const float cx = 8.f, cu = 8.f;                // xhat' = 8 xhat, U' = 8 U (see the FFN blocks' scalings in qinco_create)
+    const float sm[4] = {cx, 1.f / (cx * su), cu, 1.f / (cu * sq)};
+    if ((rc = upload(h, &h->xsmul[m], sm, 4))) return rc;
+  }
   if (h->fold2) {  // P_k = W_up[0] T_k  and  W_up[0] as fragments (ob, ib, q) for Q_g = W_up[0] U_g
     const int Dh = d.Dh;
     const float* up0 = w->up[(size_t)m * d.L];
@@ -627,6 +649,7 @@ extern "C" int qinco_create_ex(const qinco_desc* desc, const qinco_weights* w, i
   h->wx_stream.assign(d.M, nullptr);
   h->wq_stream.assign(d.M, nullptr);
   h->smul.assign(d.M, nullptr);
+  h->xsmul.assign(d.M, nullptr);
   h->K0 = d.ivf_K > 0 ? d.ivf_K : d.K;
   std::vector<int> kv(d.M, d.K);
   kv[0] = h->K0;
@@ -711,7 +734,7 @@ extern "C" int qinco_create_ex(const qinco_desc* desc, const qinco_weights* w, i
       const float so = split_weight_scale(w->out_proj[m], (size_t)d.D * d.De);
       const int og = d.D / 32 < d.Dh / 32 ? d.D / 32 : d.Dh / 32;   // = split_out_group(D, Dh)
       const size_t start = s.size();
-      for (int o0 = 0; o0 < d.D / 32; o0 += og) pack_split_kouter(s, w->out_proj[m], d.De, o0, og, so);
+      for (int o0 = 0; o0 < d.D / 32; o0 += og) pack_split_kouter(s, w->out_proj[m], d.De, d.De, o0, og, so);
       pad_to(s, start, sd.T_OUT);
       smul.push_back(1.f / (smul[0] * so));   // o = m_out acc,  acc = W_out' z' = 2^(c+s) W_out z
     } else if (sd.PROJ && !tile16) {
@@ -815,6 +838,7 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
       a.qproj = xa.qproj;
       a.ptab = h->ptab[m];
     }
+    xa.smul = h->split16 ? h->xsmul[m] : nullptr;
     HIP_TRY(h->inst->xproj(&xa, st));
     a.ttab = h->ttab[m];
   }

@@ -342,6 +342,9 @@ def main():
                 dec2 = eng2.decode(codes2.reshape(-1, cfg.M_total), check=False)
                 xs = torch.cat(batches[W:W + K])
                 blocks = 4.0 * cfg.L * cfg.De * cfg.dh - 2.0 * cfg.De * cfg.dh          # per row, block 0's up-projection folded
+                if cfg.De != cfg.D and (cfg.D // 32) % 2 == 0:
+                    blocks += 2.0 * cfg.D * cfg.De                                      # out_proj in the split form too
+                blocks += (2.0 * cfg.D * cfg.De + 2.0 * cfg.De * cfg.dh) / (cfg.A or cfg.K)   # xproj, per group
                 f16_tflops = 3.0 * blocks * (s_fpl / mlp_row) / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
                 out["split_f16"] = {
                     "value": K * args.batch / dt2, "unit": "vectors/s", "ms_per_step": dt2 / K * 1e3,
@@ -352,7 +355,7 @@ def main():
                                  "achieved_algorithmic_fp32_equivalent_tflops": s_ach,
                                  "f16_mfma_tflops_executed": f16_tflops, "peak_f16_mfma_tflops": PEAK_F16_MFMA_TFLOPS,
                                  "frac_of_f16_peak": f16_tflops / PEAK_F16_MFMA_TFLOPS},
-                    "arithmetic": "FFN blocks: fp32 operands as fp16 hi + lo, 3 fp16 MFMAs per product, fp32 accumulate; rest fp32",
+                    "arithmetic": "FFN blocks, out_proj, xproj: fp32 operands as fp16 hi + lo, 3 fp16 MFMAs per product, fp32 accumulate; tables, distances, selection fp32",
                     "note": "opt-in (QincoEngine(split_f16=True) / qinco_create_ex); parity tests: tests/test_hip_parity.py::test_split_f16_*"}
                 del dec2, xs, codes2
                 eng2.close()

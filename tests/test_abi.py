@@ -68,6 +68,27 @@ def test_shape_table(lib):
     assert lib.qinco_version().startswith(b"qinco_hip")
 
 
+def test_create_ex_validates_its_flags_before_touching_the_device(lib):
+    """qinco_create_ex: unknown flag bits are an argument error; the split-fp16 flag on a shape without a split instance (or a
+    model without FFN blocks) is QINCO_ERR_UNSUPPORTED -- both decided on the host, no GPU needed."""
+    from qinco_amd import QincoConfig, _lib, synth_state_dict
+    from qinco_amd.engine import QincoEngine
+    h = C.c_void_p()
+    d = _lib.QincoDesc(D=128, De=384, Dh=384, L=16, M=2, K=256, A=16, B=8, qinco1_mode=0, ivf_K=0, max_batch=64)
+    w = _lib.QincoWeights()
+    w.data_std = 1.0
+    assert lib.qinco_create_ex(C.byref(d), C.byref(w), 2, C.byref(h)) == -1
+    assert b"unknown flag" in lib.qinco_last_error()
+    d.Dh = 96                                   # (128, 384, 96) has no instance at all, let alone a split one
+    assert lib.qinco_create_ex(C.byref(d), C.byref(w), _lib.CREATE_SPLIT_F16, C.byref(h)) == -3
+    d.Dh, d.L = 384, 0                          # the split form peels FFN block 0: L = 0 is refused
+    assert lib.qinco_create_ex(C.byref(d), C.byref(w), _lib.CREATE_SPLIT_F16, C.byref(h)) == -3
+    assert b"split-fp16" in lib.qinco_last_error()
+    cfg = QincoConfig(D=32, M=2, K=256, L=1, de=64, dh=96)          # odd number of hidden blocks: no split instance
+    with pytest.raises(NotImplementedError, match="split-fp16"):
+        QincoEngine(cfg, synth_state_dict(cfg, 1), split_f16=True)
+
+
 def test_fails_loudly_without_gpu():
     """No CPU fallback: on a box without a GPU creating an engine must raise, not silently compute elsewhere."""
     import torch

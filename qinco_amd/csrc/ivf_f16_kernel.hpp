@@ -5,13 +5,15 @@
 // table on v_mfma_f32_32x32x16_f16 runs at the 16x higher fp16 rate, and an argmin does not need the table exactly -- it
 // needs the set of centroids that could be the argmin:
 //   pass A  s~_k = |c_k|^2 / 2 - x~.c~_k   (x~, c~ rounded to fp16, products exact, fp32 accumulate);  m~ = min_k s~_k
-//   pass B  the same table again; every k with  s~_k <= m~ + W/2  is appended to a candidate list
+//           over a SAMPLE of one eighth of the centroids (the head of the stream): m~ >= the minimum over all of them, so the
+//           threshold below only gets looser -- the argmin stays a candidate, about 8 per vector instead of 1
+//   pass B  the table over all centroids; every k with  s~_k <= m~ + W/2  is appended to a candidate list
 //   pass C  exact fp32 distance of every candidate (sequential fmaf, the association of approx_pairwise_distance) and
 //           the usual 64-bit (distance, id) atomicMin.
 // W = 2 E + 2 delta bounds |d~ - d| twice plus the fp32 evaluation error twice, so the argmin of the exact pass is always
 // a candidate:   E = 2 [(2u + u^2) + 4 D 2^-24] |x| cmax + 2^-22 sqrt(D) (|x| + cmax),  u = 2^-11 (RNE to fp16; the
 // last term covers fp16 subnormals),  delta = 4 (D + 4) 2^-24 (|x| + cmax)^2  -- Cauchy-Schwarz, rigorous, loose by
-// about sqrt(D).  Random 128-d data: about one candidate per vector.  If the list overflows, or an input is outside
+// about sqrt(D).  Random 128-d data: about one candidate per vector from the bound, seven more from the sampled minimum.  If the list overflows, or an input is outside
 // the fp16 range, a device flag makes the exact fp32 kernel (launched behind, early-exit otherwise) redo the batch.
 //
 // Kernel shape (passes A and B share it): a wave keeps VS x 32 vectors as fp16 B operands (VS = 2 for D <= 256), streams
@@ -50,6 +52,7 @@ struct IvfF16Args {
   int* cand_vec;
   int* cand_id;
   int* overflow;            // set when the list is full or an input leaves the fp16 range
+  const int* perm;          // stream position of a block -> block index (pass B: candidate ids)
 };
 
 template <int D, int MODE>
@@ -181,7 +184,7 @@ ivf_f16_kernel(IvfF16Args a) {
                 const int pos = atomicAdd(a.cand_count, 1);
                 if (pos < a.cand_cap) {
                   a.cand_vec[pos] = (int)vec[s];
-                  a.cand_id[pos] = cb * 32 + 8 * g + 4 * half + e;
+                  a.cand_id[pos] = a.perm[cb] * 32 + 8 * g + 4 * half + e;
                 } else {
                   atomicOr(a.overflow, 1);
                 }

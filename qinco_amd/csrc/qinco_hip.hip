@@ -108,6 +108,8 @@ struct qinco_handle_s {
   float* ivf_cnorm_half = nullptr;   // -|c|^2 / 2
   float ivf_cmax = 0.f;
   unsigned* ivf_amin = nullptr;      // (max_batch) approximate minima
+  int* ivf_perm = nullptr;           // stream position of a block of 32 centroids -> its index (the sample comes first)
+  int ivf_sample_blocks = 0;
   int* ivf_cand = nullptr;           // [count, overflow, pad, pad][vec (cap)][id (cap)]
   int ivf_cand_cap = 0;
 
@@ -346,13 +348,38 @@ static int build_ivf_f16(qinco_handle_s* h, const float* cb) {
     if (s2 > n2max) n2max = s2;
   }
   if (!(amax < 60000.f)) return 0;  // outside the fp16 range: the exact fp32 kernel is used on its own
+  // Stream order: a SAMPLE of the blocks first (every (nblocks / nsample)-th block, 1/8 of them), then the others.  Pass A of the
+  // filter runs over the sample only: its minimum is an upper bound of the true minimum, so the threshold it gives pass B keeps
+  // the argmin among the candidates (ivf_f16_kernel.hpp) -- at one eighth of the cost of a full pass.
+  const int nblocks = K / 32;
+  const int nsample = nblocks >= 8 ? nblocks / 8 : nblocks, sstride = nblocks / nsample;
+  std::vector<int> perm;
+  perm.reserve(nblocks);
+  std::vector<char> taken(nblocks, 0);
+  for (int i = 0; i < nsample; ++i) {
+    perm.push_back(i * sstride);
+    taken[i * sstride] = 1;
+  }
+  for (int b = 0; b < nblocks; ++b)
+    if (!taken[b]) perm.push_back(b);
+  std::vector<float> nhs(K);
   std::vector<_Float16> s((size_t)K * D + (size_t)32 * 512);   // the filter kernels' ring prefetches up to 16 fragments past the end
   size_t o = 0;
-  for (int b = 0; b < K / 32; ++b)
+  for (int p = 0; p < nblocks; ++p) {
+    const int b = perm[p];
+    for (int i = 0; i < 32; ++i) nhs[(size_t)p * 32 + i] = nh[(size_t)b * 32 + i];
     for (int k = 0; k < NK; ++k)
       for (int l = 0; l < 64; ++l)
         for (int e = 0; e < 8; ++e) s[o++] = (_Float16)cb[(size_t)(b * 32 + (l & 31)) * D + k * 16 + 8 * (l >> 5) + e];
+  }
   for (; o < s.size(); ++o) s[o] = (_Float16)0.f;
+  nh.swap(nhs);   // (stream order from here on)
+  int* dperm = nullptr;
+  int rc0 = dev_alloc(h, &dperm, (size_t)nblocks);
+  if (rc0) return rc0;
+  HIP_TRY(hipMemcpy(dperm, perm.data(), (size_t)nblocks * sizeof(int), hipMemcpyHostToDevice));
+  h->ivf_perm = dperm;
+  h->ivf_sample_blocks = nsample;
   float* dh = nullptr;
   int rc = dev_alloc(h, &dh, (s.size() + 1) / 2);
   if (rc) return rc;
@@ -421,7 +448,7 @@ static int ensure_scratch(qinco_handle_s* h) {
   if ((rc = dev_alloc(h, &h->dist, n * Cm))) return rc;
   if (d.ivf_K > 0 && (rc = dev_alloc(h, &h->ivf_best, n))) return rc;
   if (h->ivf_f16) {
-    h->ivf_cand_cap = (int)(16 * n + 4096);
+    h->ivf_cand_cap = (int)(40 * n + 4096);   // pass B keeps ~8 candidates per vector (threshold from a 1/8 sample)
     if ((rc = dev_alloc(h, &h->ivf_amin, n))) return rc;
     if ((rc = dev_alloc(h, &h->ivf_cand, 4 + 2 * (size_t)h->ivf_cand_cap))) return rc;
   }
@@ -900,9 +927,15 @@ static void launch_ivf_inst(qinco_handle_s* h, long n, int nblocks, int bps, int
                      h->ivf_stream, h->cnorm[0], nblocks, bps, h->xn, n, h->ivf_best, only_if);
 }
 
+static void ivf_grid(long tiles, int nblocks, int target_wgs, int* bps, long* slices);
+
 template <int D>
-static void launch_ivf_f16_inst(const IvfF16Args& a, long tiles, int slices, hipStream_t st) {
-  hipLaunchKernelGGL((ivf_f16_kernel<D, 0>), dim3((unsigned)tiles, (unsigned)slices), dim3(256), 0, st, a);
+static void launch_ivf_f16_inst(const IvfF16Args& a, long tiles, int slices, int sample_blocks, hipStream_t st) {
+  IvfF16Args sa = a;   // pass A: the sample at the head of the stream
+  sa.nblocks = sample_blocks;
+  long ss;
+  ivf_grid(tiles, sample_blocks, 2048, &sa.blocks_per_slice, &ss);
+  hipLaunchKernelGGL((ivf_f16_kernel<D, 0>), dim3((unsigned)tiles, (unsigned)ss), dim3(256), 0, st, sa);
   hipLaunchKernelGGL((ivf_f16_kernel<D, 1>), dim3((unsigned)tiles, (unsigned)slices), dim3(256), 0, st, a);
 }
 
@@ -938,16 +971,17 @@ static int launch_ivf_assign(qinco_handle_s* h, long n, hipStream_t st) {
     a.cand_cap = h->ivf_cand_cap;
     a.cand_vec = h->ivf_cand + 4;
     a.cand_id = h->ivf_cand + 4 + h->ivf_cand_cap;
+    a.perm = h->ivf_perm;
     const int vs = QINCO_IVF_VS(d.D);
     const long tiles = (n + 128 * vs - 1) / (128 * vs);
     long slices;
     ivf_grid(tiles, nblocks, 2048, &a.blocks_per_slice, &slices);
     switch (d.D) {
-      case 32: launch_ivf_f16_inst<32>(a, tiles, (int)slices, st); break;
-      case 96: launch_ivf_f16_inst<96>(a, tiles, (int)slices, st); break;
-      case 128: launch_ivf_f16_inst<128>(a, tiles, (int)slices, st); break;
-      case 256: launch_ivf_f16_inst<256>(a, tiles, (int)slices, st); break;
-      case 768: launch_ivf_f16_inst<768>(a, tiles, (int)slices, st); break;
+      case 32: launch_ivf_f16_inst<32>(a, tiles, (int)slices, h->ivf_sample_blocks, st); break;
+      case 96: launch_ivf_f16_inst<96>(a, tiles, (int)slices, h->ivf_sample_blocks, st); break;
+      case 128: launch_ivf_f16_inst<128>(a, tiles, (int)slices, h->ivf_sample_blocks, st); break;
+      case 256: launch_ivf_f16_inst<256>(a, tiles, (int)slices, h->ivf_sample_blocks, st); break;
+      case 768: launch_ivf_f16_inst<768>(a, tiles, (int)slices, h->ivf_sample_blocks, st); break;
       default: return fail(QINCO_ERR_UNSUPPORTED, "no IVF kernel instance for D=%d", d.D);
     }
     HIP_TRY(hipGetLastError());

@@ -322,4 +322,133 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same table + top-T for SMALL launches (G <= 16 384 groups, e.g. the reference's default batch of 1024 vectors with 8
+// beams): dist_topk_mfma_kernel fills the chip only with 8 groups per wave, and each of those waves still pays a full 32-column
+// table (32.8 k MFMA cycles at D = 128) before it selects anything: 27 us per step at 8192 groups, 18 % of a split-form
+// qinco2-S step.  Here the four waves of a workgroup share 32 groups: every wave computes a quarter of the codewords for all 32
+// (8.2 k MFMA cycles), the distances meet in one LDS table, and after a barrier each wave selects 8 of the groups.
+// ---------------------------------------------------------------------------------------------
+template <int D, int NKB>
+__global__ void __launch_bounds__(256)
+dist_topk_mfma_coop_kernel(const float* __restrict__ x, const float* __restrict__ xhat, int F,
+                           const f32x4* __restrict__ cstream, const float* __restrict__ cnorm, long G, int T,
+                           int* __restrict__ ids_out) {
+  constexpr int NDB = D / 32, K = NKB * 32, LDK = K + 4, SGP = 4, CPW = NKB / 4;   // codeword blocks per wave
+  static_assert(NKB % 4 == 0, "the codeword blocks are split over four waves");
+  __shared__ __attribute__((aligned(16))) float table[32 * LDK];
+  __shared__ unsigned long long surv_all[4 * SGP * SEL_SURV];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, half = lane >> 5;
+  const long g0 = (long)blockIdx.x * 32;
+  long g = g0 + j;
+  if (g >= G) g = G - 1;
+  const float* xp = x + (g / F) * D + half * 4;
+  const float* hp = xhat ? xhat + g * D + half * 4 : nullptr;
+  // fragment (cb, ib, q) of the stream = 64 lanes x float4 at ((cb * NDB + ib) * 4 + q) * 64
+  const f32x4* wp = cstream + (long)(wave * CPW) * NDB * 4 * 64 + lane;
+  f32x16 acc[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+  float rn = 0.f;
+#pragma unroll
+  for (int ib = 0; ib < NDB; ++ib) {
+    f32x16 rb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(xp + ib * 32 + 8 * q);
+      if (hp) {
+        const f32x4 hq = *reinterpret_cast<const f32x4*>(hp + ib * 32 + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = __fsub_rn(t[e], hq[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        rb[4 * q + e] = t[e];
+        rn = fmaf(t[e], t[e], rn);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 w = wp[((c * NDB + ib) * 4 + q) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], rb[4 * q + e], acc[c], 0, 0, 0);
+      }
+  }
+  rn += __shfl_xor(rn, 32);
+  // distances (|r|^2 + |c|^2) - 2 r.c (the reference's association, utils.py:336-346) into row j of the shared table
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    const int cb = wave * CPW + c;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + cb * 32 + 8 * gq + 4 * half);
+      f32x4 d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = __fsub_rn(__fadd_rn(rn, cn[e]), __fmul_rn(2.f, acc[c][4 * gq + e]));
+      *reinterpret_cast<f32x4*>(table + j * LDK + cb * 32 + 8 * gq + 4 * half) = d;
+    }
+  }
+  __syncthreads();
+  unsigned long long* surv = surv_all + wave * SGP * SEL_SURV;
+  const long gend = G - g0 < 32 ? G - g0 : 32;
+  const int r_lo = wave * 8, r_hi = r_lo + 8 < gend ? r_lo + 8 : (int)gend;   // this wave's rows of the table
+  if (T > 1 && T <= 64) {
+    for (int r0 = r_lo; r0 < r_hi; r0 += SGP) {
+      int rank[SGP], index[SGP];
+      const unsigned ok = wave_select_smallest_multi<SGP, K / 64>(table + r0 * LDK, LDK, T, surv, lane, rank, index);
+#pragma unroll
+      for (int u = 0; u < SGP; ++u) {
+        const int r = r0 + u;
+        if (r >= r_hi) break;
+        if ((ok >> u) & 1) {
+          if (rank[u] >= 0) ids_out[(g0 + r) * T + rank[u]] = index[u];
+          continue;
+        }
+        float* dg = table + r * LDK;   // massive exact ties: the arg-min rounds
+        for (int t = 0; t < T; ++t) {
+          float bv = __builtin_inff();
+          int bi = 0x7fffffff;
+#pragma unroll
+          for (int k = lane; k < K; k += 64) {
+            const float v = dg[k];
+            const bool take = v < bv;
+            bv = take ? v : bv;
+            bi = take ? k : bi;
+          }
+          wave_argmin(bv, bi);
+          if (bi == 0x7fffffff) bi = 0;
+          if (lane == 0) ids_out[(g0 + r) * T + t] = bi;
+          if ((bi & 63) == lane) dg[bi] = __builtin_inff();
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  } else {
+    for (int r = r_lo; r < r_hi; ++r) {   // T == 1 or T > 64: rounds of wave arg-min (see dist_topk_mfma_kernel)
+      float* dg = table + r * LDK;
+      for (int t = 0; t < T; ++t) {
+        float bv = __builtin_inff();
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int k = lane; k < K; k += 64) {
+          const float v = dg[k];
+          const bool take = v < bv;
+          bv = take ? v : bv;
+          bi = take ? k : bi;
+        }
+        wave_argmin(bv, bi);
+        if (bi == 0x7fffffff) bi = 0;
+        if (lane == 0) ids_out[(g0 + r) * T + t] = bi;
+        if ((bi & 63) == lane) dg[bi] = __builtin_inff();
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+}
+
 }  // namespace qinco

@@ -895,7 +895,13 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
 template <int D>
 static void launch_table_inst(const float* x, const float* xhat, int F, const f32x4* cs, const float* cn, long G, int T,
                               int* ids, hipStream_t st) {
-  const int gpw = G <= 16384 ? 8 : 32;  // small launches: 8 groups per wave (selection latency, see the kernel)
+  static const bool coop = getenv("QINCO_TABLE_NO_COOP") == nullptr;
+  if (G <= 16384 && coop) {   // small launches: the four waves of a workgroup share 32 groups (ivf_kernel.hpp)
+    hipLaunchKernelGGL((dist_topk_mfma_coop_kernel<D, 8>), dim3((unsigned)((G + 31) / 32)), dim3(256), 0, st, x, xhat, F, cs, cn, G, T,
+                       ids);
+    return;
+  }
+  const int gpw = G <= 16384 ? 8 : 32;  // (QINCO_TABLE_NO_COOP: small launches with 8 groups per wave, the round-2 form)
   hipLaunchKernelGGL((dist_topk_mfma_kernel<D, 8>), dim3((unsigned)((G + 4 * gpw - 1) / (4 * gpw))), dim3(256), 0, st, x, xhat,
                      F, cs, cn, G, T, ids, gpw);
 }

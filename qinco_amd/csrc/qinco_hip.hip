@@ -896,7 +896,8 @@ template <int D>
 static void launch_table_inst(const float* x, const float* xhat, int F, const f32x4* cs, const float* cn, long G, int T,
                               int* ids, hipStream_t st) {
   static const bool coop = getenv("QINCO_TABLE_NO_COOP") == nullptr;
-  if (G <= 16384 && coop) {   // small launches: the four waves of a workgroup share 32 groups (ivf_kernel.hpp)
+  static const long coop_max = [] { const char* e = getenv("QINCO_TABLE_COOP_MAX"); return e ? atol(e) : 16384L; }();
+  if (G <= coop_max && coop) {   // small launches: the four waves of a workgroup share 32 groups (ivf_kernel.hpp)
     hipLaunchKernelGGL((dist_topk_mfma_coop_kernel<D, 8>), dim3((unsigned)((G + 31) / 32)), dim3(256), 0, st, x, xhat, F, cs, cn, G, T,
                        ids);
     return;

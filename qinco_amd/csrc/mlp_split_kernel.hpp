@@ -71,6 +71,97 @@ QINCO_INL void lds_arrived4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
+// The workgroup-shared LDS-DMA weight ring of the split-form kernels (P fragments of 1 KiB, groups of G = 16, each of the four
+// waves DMAs PER = 4 fragments of a group).  Protocol at the boundary in front of group g of the stream: every LDS read this
+// wave has issued -- the previous group's -- has completed (lgkmcnt(0); hipcc would otherwise let that wait, and the MFMAs
+// behind it, sink below the barrier that lets the other waves refill the group: mlp_kernel.hpp, fragmm); this wave's DMAs of
+// group g have landed (it has issued NG-1 groups beyond the ones already consumed, so "at most (NG-2) x PER outstanding" means
+// the oldest of them is complete; younger loads / stores of the wave only make the wait stricter); barrier; the previous group's
+// slots are refilled with the group NG-1 ahead.  Sections of the stream are multiples of P, so ring slots are compile-time
+// constants; `wsrc` is the origin of the current section.
+template <int P>
+struct SplitRing {
+  static constexpr int G = 16, NG = P / G, PER = G / 4;
+  const f32x4* wsrc;
+  f32x4* wdst;
+  unsigned addr, addr_hi;
+  QINCO_INL void init(const f32x4* stream, f32x4* lds, int lane, int wave_u) {
+    wsrc = stream + lane + wave_u * PER * 64;
+    wdst = lds + wave_u * PER * 64;
+    addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds + lane * 16;
+    addr_hi = addr + 48 * 1024;
+  }
+  template <int T0>
+  QINCO_INL void dma_group() {
+    static_for<PER>([&]<int q>() QINCO_LAMBDA { dma<T0 + G - P, q>(); });
+  }
+  template <int T, int q>   // the q-th DMA of the refill that belongs to the boundary in front of fragment T
+  QINCO_INL void dma() {
+    if constexpr (q < PER)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (T + P - G + q) * 64),
+                                       (__attribute__((address_space(3))) void*)(wdst + ((T + P - G + q) % P) * 64), 16, 0, 0);
+  }
+  QINCO_INL void prologue() {
+    static_for<NG - 1>([&]<int i>() QINCO_LAMBDA { dma_group<i * G>(); });
+  }
+  template <int T>
+  QINCO_INL void sync() {
+    if constexpr (T % G == 0) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0070 | (((NG - 2) * PER) & 15) | ((((NG - 2) * PER) >> 4) << 14));
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  template <int T, int q>
+  QINCO_INL void read(f32x4& dst) {
+    constexpr int slot = (T + q) % P;
+    if constexpr (slot < 48) lds_read128<slot * 1024>(dst, addr); else lds_read128<(slot - 48) * 1024>(dst, addr_hi);
+  }
+  template <int T>
+  QINCO_INL void ldquad(f32x4 (&dst)[4]) {
+    sync<T>();
+    if constexpr (T % G == 0) static_for<PER>([&]<int q>() QINCO_LAMBDA { dma<T, q>(); });
+    static_for<4>([&]<int q>() QINCO_LAMBDA { read<T, q>(dst[q]); });
+  }
+  // one step: the six MFMAs of quad `cur` with the ring traffic of the next quad (fragments TN ..) spread between them
+  template <int TN, class F>
+  QINCO_INL void step(f32x4 (&cur)[4], f32x4 (&nxt)[4], f32x16& t0, f32x16& t1, const f16x8& bh, const f16x8& bl, F&& extra) {
+#define QINCO_SB __builtin_amdgcn_sched_barrier(0)
+#define QINCO_H(v) __builtin_bit_cast(f16x8, v)
+    t0 = QINCO_MFMA_H(QINCO_H(cur[0]), bh, t0);  QINCO_SB;
+    sync<TN>();                                  QINCO_SB;
+    t1 = QINCO_MFMA_H(QINCO_H(cur[2]), bh, t1);  QINCO_SB;
+    read<TN, 0>(nxt[0]);
+    read<TN, 1>(nxt[1]);                         QINCO_SB;
+    t0 = QINCO_MFMA_H(QINCO_H(cur[0]), bl, t0);  QINCO_SB;
+    read<TN, 2>(nxt[2]);
+    read<TN, 3>(nxt[3]);                         QINCO_SB;
+    t1 = QINCO_MFMA_H(QINCO_H(cur[2]), bl, t1);  QINCO_SB;
+    if constexpr (TN % G == 0) { dma<TN, 0>(); dma<TN, 1>(); }
+    QINCO_SB;
+    t0 = QINCO_MFMA_H(QINCO_H(cur[1]), bh, t0);  QINCO_SB;
+    if constexpr (TN % G == 0) { dma<TN, 2>(); dma<TN, 3>(); }
+    QINCO_SB;
+    t1 = QINCO_MFMA_H(QINCO_H(cur[3]), bh, t1);
+    extra();
+    QINCO_SB;
+#undef QINCO_H
+#undef QINCO_SB
+    lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
+    static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
+  }
+  template <int FROM, int TO>   // the padding of a section, then the next section's origin
+  QINCO_INL void end_section(f32x4 (&cur)[4], f32x4 (&nxt)[4]) {
+    static_for<(TO - FROM) / 4>([&]<int i>() QINCO_LAMBDA {
+      ldquad<FROM + 4 * i + 4>(nxt);
+      lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
+      static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
+    });
+    wsrc += TO * 64;
+  }
+};
+
 // out_proj (D x De) takes the split form when it exists and has an even number of output blocks (host packer and kernel)
 constexpr bool split_out_proj(int D, int DE) { return D != DE && (D / 32) % 2 == 0; }
 // output blocks per out_proj pass: they accumulate in y's registers
@@ -114,55 +205,9 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   // ---- weight ring ------------------------------------------------------------------------------------
   __shared__ f32x4 lds_ring[P * 64];
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const f32x4* wsrc = a.wstream + lane + wave_u * PER * 64;   // origin of the current section (sections are multiples of P)
-  f32x4* wdst = lds_ring + wave_u * PER * 64;                 // ... + this wave's share of a group
-  auto dma_group = [&]<int T0>() QINCO_LAMBDA {            // fragments T0 .. T0+15 of the section -> their ring slots
-    static_for<PER>([&]<int q>() QINCO_LAMBDA {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (T0 + q) * 64),
-                                       (__attribute__((address_space(3))) void*)(wdst + ((T0 + q) % P) * 64), 16, 0, 0);
-    });
-  };
-  const unsigned ring_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds_ring + lane * 16;
-  const unsigned ring_addr_hi = ring_addr + 48 * 1024;   // (the offset field of a DS instruction is 16 bits)
-  // Quad T .. T+3 of the current section -> dst.  At a group boundary: every LDS read this wave has issued -- the previous
-  // group's -- has completed (lgkmcnt(0); hipcc would otherwise let that wait, and the MFMAs behind it, sink below the barrier
-  // that lets the other waves refill the group: mlp_kernel.hpp, fragmm), this wave's DMAs of the new group have landed (it
-  // has issued NG-1 groups beyond the ones already consumed, so "at most (NG-2) x PER outstanding" means the oldest of them
-  // is complete; younger loads / stores of the wave only make the wait stricter), and past the barrier the previous
-  // group's slots are refilled with the group NG-1 ahead.
-  auto ldquad = [&]<int T>(f32x4 (&dst)[4]) QINCO_LAMBDA {
-    if constexpr (T % G == 0) {
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0x0070 | (((NG - 2) * PER) & 15) | ((((NG - 2) * PER) >> 4) << 14));   // vmcnt(N) + lgkmcnt(0)
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      dma_group.template operator()<T + P - G>();
-    }
-    static_for<4>([&]<int q>() QINCO_LAMBDA {
-      constexpr int slot = (T + q) % P;
-      if constexpr (slot < 48) lds_read128<slot * 1024>(dst[q], ring_addr); else lds_read128<(slot - 48) * 1024>(dst[q], ring_addr_hi);
-    });
-  };
-  // the same, in the pieces a step spreads between its MFMAs
-  auto ring_sync = [&]<int T>() QINCO_LAMBDA {
-    if constexpr (T % G == 0) {
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0x0070 | (((NG - 2) * PER) & 15) | ((((NG - 2) * PER) >> 4) << 14));
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-  };
-  auto ring_dma = [&]<int T, int q>() QINCO_LAMBDA {
-    if constexpr (T % G == 0 && q < PER)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (T + P - G + q) * 64),
-                                       (__attribute__((address_space(3))) void*)(wdst + ((T + P - G + q) % P) * 64), 16, 0, 0);
-  };
-  auto ring_read = [&]<int T, int q>(f32x4& dst) QINCO_LAMBDA {
-    constexpr int slot = (T + q) % P;
-    if constexpr (slot < 48) lds_read128<slot * 1024>(dst, ring_addr); else lds_read128<(slot - 48) * 1024>(dst, ring_addr_hi);
-  };
+  SplitRing<P> ring;
+  ring.init(a.wstream, lds_ring, lane, wave_u);
   static_assert(PER <= 4, "a step carries at most four DMAs");
-  auto as16 = [](const f32x4& v) QINCO_LAMBDA { return __builtin_bit_cast(f16x8, v); };
 
   const float zs = a.smul[0], zsi = a.smul[1];
 
@@ -269,12 +314,12 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
     // every wave is done with its staging buffer before anybody's DMA lands in the ring
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    static_for<NG - 1>([&]<int i>() QINCO_LAMBDA { dma_group.template operator()<i * G>(); });
+    ring.prologue();
   }
 
   f32x4 cur[4], nxt[4];
   stamp(1);   // head operands assembled
-  ldquad.template operator()<0>(cur);
+  ring.template ldquad<0>(cur);
   lds_arrived4(cur[0], cur[1], cur[2], cur[3]);
   stamp(2);   // first quad of the stream in registers
 
@@ -284,39 +329,10 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   // Everything is pinned by scheduling barriers: left alone, hipcc hoists the MFMAs above the reads (the wait then exposes
   // the LDS latency in every step), and a wave that issues its four reads and four DMAs in one go leaves the pipe idle.
   auto step = [&]<int TN>(f32x16& t0, f32x16& t1, const f16x8& bh, const f16x8& bl, auto&& extra) QINCO_LAMBDA {
-#define QINCO_SB __builtin_amdgcn_sched_barrier(0)
-    // (the reads go first: the last one has four MFMAs = 128 cycles to land before the wait; with one read per gap the last had
-    // 32 and every step stalled on it)
-    t0 = QINCO_MFMA_H(as16(cur[0]), bh, t0);  QINCO_SB;
-    ring_sync.template operator()<TN>();      QINCO_SB;
-    t1 = QINCO_MFMA_H(as16(cur[2]), bh, t1);  QINCO_SB;
-    ring_read.template operator()<TN, 0>(nxt[0]);
-    ring_read.template operator()<TN, 1>(nxt[1]);  QINCO_SB;
-    t0 = QINCO_MFMA_H(as16(cur[0]), bl, t0);  QINCO_SB;
-    ring_read.template operator()<TN, 2>(nxt[2]);
-    ring_read.template operator()<TN, 3>(nxt[3]);  QINCO_SB;
-    t1 = QINCO_MFMA_H(as16(cur[2]), bl, t1);  QINCO_SB;
-    ring_dma.template operator()<TN, 0>();
-    ring_dma.template operator()<TN, 1>();    QINCO_SB;
-    t0 = QINCO_MFMA_H(as16(cur[1]), bh, t0);  QINCO_SB;
-    ring_dma.template operator()<TN, 2>();
-    ring_dma.template operator()<TN, 3>();    QINCO_SB;
-    t1 = QINCO_MFMA_H(as16(cur[3]), bh, t1);
-    extra();
-    QINCO_SB;
-#undef QINCO_SB
-    lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
-    static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
+    ring.template step<TN>(cur, nxt, t0, t1, bh, bl, extra);
   };
   // the rest of a section (padding up to a multiple of P): read and drop, the ring protocol keeps running
-  auto end_section = [&]<int FROM, int TO>() QINCO_LAMBDA {
-    static_for<(TO - FROM) / 4>([&]<int i>() QINCO_LAMBDA {
-      ldquad.template operator()<FROM + 4 * i + 4>(nxt);
-      lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
-      static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
-    });
-    wsrc += TO * 64;
-  };
+  auto end_section = [&]<int FROM, int TO>() QINCO_LAMBDA { ring.template end_section<FROM, TO>(cur, nxt); };
   // accumulators of hidden block ob -> B operands of the down-projection, in place
   auto convert_y = [&]<int ob>(float mup) QINCO_LAMBDA {
     f32x16 v = y[ob];
@@ -462,7 +478,7 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
         static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
           constexpr int T = (ob * NEB + ib) * 4;     // fragments q = 0..3 of block pair (ob, ib): fp32 A operands, 4 MFMAs each
           const f32x16 zb = zget.template operator()<ib>();
-          ldquad.template operator()<T + 4>(nxt);
+          ring.template ldquad<T + 4>(nxt);
           __builtin_amdgcn_sched_barrier(0);
           static_for<4>([&]<int q>() QINCO_LAMBDA {
             static_for<4>([&]<int e4>() QINCO_LAMBDA { o = QINCO_MFMA(cur[q][e4], zb[4 * q + e4], o); });
@@ -501,89 +517,6 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
 // Stream: [U section: for ib < D/32: for c: for o < De/32: hi, lo][Q section: for ib < De/32: for c: for o < Dh/32: hi, lo].
 // smul = [2^cx, 1 / (2^cx s_u), 2^cu, 1 / (2^cu s_q)].
 // ------------------------------------------------------------------------------------------------------------------------
-template <int P>
-struct SplitRing {   // the workgroup-shared LDS-DMA ring of mlp_split_kernel as an object (same protocol, same comments apply)
-  static constexpr int G = 16, NG = P / G, PER = G / 4;
-  const f32x4* wsrc;
-  f32x4* wdst;
-  unsigned addr, addr_hi;
-  QINCO_INL void init(const f32x4* stream, f32x4* lds, int lane, int wave_u) {
-    wsrc = stream + lane + wave_u * PER * 64;
-    wdst = lds + wave_u * PER * 64;
-    addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds + lane * 16;
-    addr_hi = addr + 48 * 1024;
-  }
-  template <int T0>
-  QINCO_INL void dma_group() {
-    static_for<PER>([&]<int q>() QINCO_LAMBDA { dma<T0 + G - P, q>(); });
-  }
-  template <int T, int q>   // the q-th DMA of the refill that belongs to the boundary in front of fragment T
-  QINCO_INL void dma() {
-    if constexpr (q < PER)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (T + P - G + q) * 64),
-                                       (__attribute__((address_space(3))) void*)(wdst + ((T + P - G + q) % P) * 64), 16, 0, 0);
-  }
-  QINCO_INL void prologue() {
-    static_for<NG - 1>([&]<int i>() QINCO_LAMBDA { dma_group<i * G>(); });
-  }
-  template <int T>
-  QINCO_INL void sync() {
-    if constexpr (T % G == 0) {
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0x0070 | (((NG - 2) * PER) & 15) | ((((NG - 2) * PER) >> 4) << 14));
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-  }
-  template <int T, int q>
-  QINCO_INL void read(f32x4& dst) {
-    constexpr int slot = (T + q) % P;
-    if constexpr (slot < 48) lds_read128<slot * 1024>(dst, addr); else lds_read128<(slot - 48) * 1024>(dst, addr_hi);
-  }
-  template <int T>
-  QINCO_INL void ldquad(f32x4 (&dst)[4]) {
-    sync<T>();
-    if constexpr (T % G == 0) static_for<PER>([&]<int q>() QINCO_LAMBDA { dma<T, q>(); });
-    static_for<4>([&]<int q>() QINCO_LAMBDA { read<T, q>(dst[q]); });
-  }
-  // one step: the six MFMAs of quad `cur` with the ring traffic of the next quad (fragments TN ..) spread between them
-  template <int TN, class F>
-  QINCO_INL void step(f32x4 (&cur)[4], f32x4 (&nxt)[4], f32x16& t0, f32x16& t1, const f16x8& bh, const f16x8& bl, F&& extra) {
-#define QINCO_SB __builtin_amdgcn_sched_barrier(0)
-#define QINCO_H(v) __builtin_bit_cast(f16x8, v)
-    t0 = QINCO_MFMA_H(QINCO_H(cur[0]), bh, t0);  QINCO_SB;
-    sync<TN>();                                  QINCO_SB;
-    t1 = QINCO_MFMA_H(QINCO_H(cur[2]), bh, t1);  QINCO_SB;
-    read<TN, 0>(nxt[0]);
-    read<TN, 1>(nxt[1]);                         QINCO_SB;
-    t0 = QINCO_MFMA_H(QINCO_H(cur[0]), bl, t0);  QINCO_SB;
-    read<TN, 2>(nxt[2]);
-    read<TN, 3>(nxt[3]);                         QINCO_SB;
-    t1 = QINCO_MFMA_H(QINCO_H(cur[2]), bl, t1);  QINCO_SB;
-    if constexpr (TN % G == 0) { dma<TN, 0>(); dma<TN, 1>(); }
-    QINCO_SB;
-    t0 = QINCO_MFMA_H(QINCO_H(cur[1]), bh, t0);  QINCO_SB;
-    if constexpr (TN % G == 0) { dma<TN, 2>(); dma<TN, 3>(); }
-    QINCO_SB;
-    t1 = QINCO_MFMA_H(QINCO_H(cur[3]), bh, t1);
-    extra();
-    QINCO_SB;
-#undef QINCO_H
-#undef QINCO_SB
-    lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
-    static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
-  }
-  template <int FROM, int TO>   // the padding of a section, then the next section's origin
-  QINCO_INL void end_section(f32x4 (&cur)[4], f32x4 (&nxt)[4]) {
-    static_for<(TO - FROM) / 4>([&]<int i>() QINCO_LAMBDA {
-      ldquad<FROM + 4 * i + 4>(nxt);
-      lds_arrived4(nxt[0], nxt[1], nxt[2], nxt[3]);
-      static_for<4>([&]<int q>() QINCO_LAMBDA { cur[q] = nxt[q]; });
-    });
-    wsrc += TO * 64;
-  }
-};
-
 template <int D, int DE, int DH, int P>
 __global__ void __launch_bounds__(256, 1) xproj_split_kernel(XprojArgs a) {
   constexpr int NDB = D / 32, NEB = DE / 32, NHB = DH / 32;

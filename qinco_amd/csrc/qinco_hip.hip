@@ -661,6 +661,11 @@ extern "C" int qinco_create_ex(const qinco_desc* desc, const qinco_weights* w, i
     return code;
   };
   if (hipGetDevice(&h->device) != hipSuccess) return bail(fail(QINCO_ERR_HIP, "hipGetDevice failed (no HIP device?)"));
+  if (h->split16) {   // the split-form kernel of the 384-wide shapes uses all 160 KiB of a gfx950 CU's LDS (ring + parked z')
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) != hipSuccess || lds < 160 * 1024)
+      return bail(fail(QINCO_ERR_UNSUPPORTED, "qinco_create_ex: the split-fp16 kernels need 160 KiB of LDS per workgroup (device: %d B)", lds));
+  }
   if ((rc = upload(h, &h->mean, w->data_mean, d.D))) return bail(rc);
 
   h->codebook.assign(d.M, nullptr);

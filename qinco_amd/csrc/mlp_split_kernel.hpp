@@ -1,15 +1,16 @@
-// Split-fp16 form of the fused codeword-MLP kernel (VAR bit 512; opt-in: qinco_create_ex flag QINCO_FLAG_SPLIT_F16).
+// Split-fp16 form of the fused codeword-MLP kernel (VAR bit 512; opt-in: qinco_create_ex flag QINCO_CREATE_SPLIT_F16) and of
+// its per-group pre-GEMM (xproj_split_kernel, at the end of this file).
 //
 // Same function, tile (a wave owns 32 rows and all features), folded head (z = T[cid] + U[group], y = relu(P[cid] + Q[group]))
-// and fp32 tail (out_proj, candidate, distance) as mlp_kernel.hpp -- only the L residual FFN blocks, 94 % of the FLOPs at the
-// qinco2-L shape, are evaluated differently: fp32-in MFMA runs at the f32 vector rate on gfx950 (1/16 of the fp16 rate), so
-// each fp32 operand is split into two fp16 values, v = hi + lo with hi = fp16(v), lo = fp16(v - hi) (22 significand bits), and
+// and fp32 candidate / distance epilogue as mlp_kernel.hpp -- the GEMMs (the L residual FFN blocks, 94 % of the FLOPs at the
+// qinco2-L shape, and out_proj when D has an even number of 32-blocks) are evaluated differently: fp32-in MFMA runs at the f32
+// vector rate on gfx950 (1/16 of the fp16 rate), so each fp32 operand is split into two fp16 values, v = hi + lo with hi = fp16(v), lo = fp16(v - hi) (22 significand bits), and
 //     W.x  ~=  Whi.xhi + Whi.xlo + Wlo.xhi            (the dropped Wlo.xlo term is 2^-22 relative)
 // on v_mfma_f32_32x32x16_f16 with fp32 accumulation: three MFMAs of 32 cycles for the K = 16 that costs eight fp32 MFMAs of
 // 64 cycles.  Every product of two fp16 values is exact in fp32, the accumulation is fp32 as before; measured against
 // float64 the result is in the same error class as the fp32 MFMA chain (scripts/ubench/split16.hip: 2.5e-7 vs 2.3e-7 rms at
 // K = 384).  fp16 has 5 exponent bits: a lo part below 2^-14 is subnormal and loses bits, so the operands are kept at
-// magnitudes where that does not matter by exact power-of-two scalings chosen on the host (qinco_hip.hip, split_scales):
+// magnitudes where that does not matter by exact power-of-two scalings chosen on the host (qinco_hip.hip, qinco_create_ex):
 //     z is held as z' = 2^c z, h as h' = 2^a h, W_up' = 2^d W_up, W_down' = 2^b W_down (d, b per layer) and the chain
 //     accumulators are scaled back by one fp32 multiply in the epilogue they need anyway (smul[] below).
 //

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- encode throughput of the MI355X QINCo2 engine on BASELINE.json's metric.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload C2] [--batch 16384]
+    python bench.py [--gpus N --steps K --warmup W] [--workload C2] [--batch 16384] [--scaling weak|strong]
 
 `--gpus N` with N > 1 works both ways: pre-launched (the driver's `python -m torch.distributed.run --nnodes=1
 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE in the
@@ -10,9 +10,15 @@ rank per GPU (like the reference's `accelerate launch --multi_gpu`, run.sh:8).
 
 A "step" = one pass of the hot path (model(x, step="encode")) over one batch of `--batch` synthetic fp32 vectors per
 GPU.  Every step (and every warm-up step) encodes a DIFFERENT batch; all batches are generated on the device before the
-timed region (inputs resident in HBM).  Weak scaling: every rank encodes its own shard of the synthetic database
-(contiguous range sharding like search_tasks.py:103-104, no data-path collective); the uint8 codes of all timed steps are
-gathered to rank 0 over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+timed region (inputs resident in HBM).  Sharding is the reference's (contiguous ranges, search_tasks.py:103-104), no
+data-path collective; the uint8 codes of all timed steps are gathered to rank 0 over RCCL inside the timed region.
+  --scaling weak   (default, the driver's form): every rank encodes K batches of its own -> work grows with N;
+  --scaling strong: ONE database of K x batch vectors (or --db N) is split over the ranks like encode_database does
+                    (the north_star's "1B-vector encode" statement); a step is then 1/K of the whole job.
+Control plane (barriers, timing exchange) runs on a gloo group, the payload gather on RCCL (`--backend nccl`); if RCCL
+cannot be initialised or the gather raises, the ranks fall back to per-rank part files (the reference's own output format)
+and the line says so in multi_gpu.gather -- a scaling run still yields per-rank vectors/s.  Each rank binds itself to the
+CPU set of its GPU's NUMA node (qinco_amd/affinity.py).  Rank 0 prints ONE JSON line.
 
 metric/unit: encode vectors/s (BASELINE.json "metric"); workload C2 = qinco2-L 8x8, D=128, A=16, B=8
 (BASELINE.json configs[1]) with seeded synthetic weights (no trained checkpoints offline).
@@ -21,10 +27,14 @@ launch (rows x R_mlp) / mean launch duration measured with HIP eve
 achieved / peak.  The kernel folds the row-independent head of the MLP out, so the matrix pipe executes
 fewer FLOPs than the algorithm counts: `frac_executed` = executed FLOPs / duration / peak is the pipe-utilisation figure
 (it cannot exceed 1; the algorithmic one can on short models).
-Also in the line (N = 1, measured after the timed region): `decode` (vectors/s + its roofline), `mse` of
-encode -> decode over the timed batches (AnyVectMSE, metrics.py:51-58), `beam1` (greedy encode), `batch_1024` (encode at
-the reference's default batch, qinco_cfg.yaml:38), `split_f16` (the opt-in split-fp16 form of the FFN blocks on the same
-batches: vectors/s, the code rows that differ from the fp32 path's, MSE; never the headline `value`).
+Also in the line (N = 1, measured after the timed region):
+  `decode`, `mse`, `beam1`, `batch_1024`, `split_f16` -- as in round 2;
+  `c1` -- BASELINE configs[0] / the north_star's literal target (qinco1 8x8, greedy): vectors/s, roofline, the number of
+          code rows equal to the oracle's on a 256-vector sample, and the oracle's own rate on that sample (CPU baseline);
+  `c3`, `c4` -- BASELINE configs[2] (M = 16) and configs[3] (D = 768) at their bench batch, with roofline;
+  `encode_db_bvecs` -- the actual `task=encode` data path (search_tasks.py:85-137): a uint8 .bvecs file on disk ->
+          get_data_memmap -> encode_database(QINCoHIP) -> part file, i.e. host buffers / PCIe included, next to the
+          HBM-resident rate of the same model.
 cpu_baseline: the oracle restatement with its codeword MLP on torch CPU ops (oracle/qinco_oracle.py, backend "torch":
 same op sequence as the reference's CPU path, codes equal to the numpy oracle and to the imported reference) timed on
 this box's host cores at the reference's batch of 1024 on a bounded sample.
@@ -37,6 +47,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -50,13 +61,15 @@ PEAK_F16_MFMA_TFLOPS = 2516.6   # dense fp16 / bf16 MFMA peak at 2.4 GHz (16 x t
 # measured in the build container (8 cores, C2, 256 vectors): imported reference wrapper 46.5 vec/s,
 # this port (torch backend) 42.3 vec/s, numpy oracle 9.3 vec/s -- all three give identical codes
 REF_OVER_PORT_CONTAINER = 1.10
+WORKLOAD_NAMES = {"C1": "C1: qinco1 8x8 greedy encode", "C2": "C2: qinco2-L 8x8 encode", "C3": "C3: qinco2-L 16x8 encode",
+                  "C4": "C4: qinco2-L 8x8 encode, D=768"}
 
 
 def pmc_traffic_per_row():
     """L2<->fabric bytes per MLP row from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
     WRITE_SIZE).  Counters cannot be read from inside this process, so the figure of the separate PMC run of this
     same command is scaled to this run's rows per launch."""
-    for name in ("r02_c2_traffic.json", "r01_c2_traffic.json"):
+    for name in ("r03_c2_traffic.json", "r02_c2_traffic.json", "r01_c2_traffic.json"):
         try:
             with open(ROOT / "profiles" / name) as f:
                 return float(json.load(f)["bytes_per_row"]), name
@@ -65,16 +78,21 @@ def pmc_traffic_per_row():
     return None, None
 
 
+def cpu_threads(torch) -> int:
+    # The reference's own CPU protocol runs 32 ATen threads (qinco_tasks.py:492).  On this box (128 cores) more threads are
+    # slower: 16 / 32 / 64 / 128 threads gave 39 / 41 / 33 / 20 vectors/s at batch 1024 (profiles/r02_cpu_sweep.jsonl).
+    threads = min(32, int(torch.get_num_threads()))
+    torch.set_num_threads(threads)
+    return threads
+
+
 def cpu_baseline(cfg, sd, budget_s: float = 20.0, chunk: int = 1024):
     """Oracle encode throughput on the host cores (rank 0, N=1 only): bounded sample of the same workload at the
     reference's default batch (qinco_cfg.yaml:38), ATen threads = the cores torch picked (stated)."""
     import torch
     from oracle.qinco_oracle import OracleQINCo
     from qinco_amd import synth_vectors
-    # The reference's own CPU protocol runs 32 ATen threads (qinco_tasks.py:492).  On this box (128 cores) more threads are
-    # slower: 16 / 32 / 64 / 128 threads gave 39 / 41 / 33 / 20 vectors/s at batch 1024 (profiles/r02_cpu_sweep.jsonl).
-    threads = min(32, int(torch.get_num_threads()))
-    torch.set_num_threads(threads)
+    threads = cpu_threads(torch)
     oracle = OracleQINCo.from_config(cfg, sd, backend="torch")
     x = synth_vectors(cfg, sd, 16 * chunk, seed=4242)
     oracle(x[:64], step="encode")  # warm-up
@@ -119,6 +137,139 @@ def synth_batch_device(torch, cfg, mean_t, std, n, seed, dev):
     return z * std + mean_t
 
 
+def mlp_roofline(pr):
+    launches = max(pr["mlp_launches"], 1)
+    avg_ms = pr["mlp_ms"] / launches
+    fpl = pr["mlp_flops"] / launches
+    ach = fpl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    return launches, avg_ms, fpl, ach
+
+
+def executed_share(cfg, Ae):
+    """FOLD / FOLD2 (mlp_kernel.hpp): the row-independent head of the MLP is not recomputed per row, so the MFMA executes
+    fewer FLOPs than the reference's algorithm counts.  Share of the algorithmic FLOPs the matrix pipe really executes."""
+    head = (2.0 * cfg.D * cfg.De if cfg.De != cfg.D else 0.0) + 2.0 * (cfg.De + cfg.D) * cfg.De   # FOLD
+    head += 2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0                                            # FOLD2
+    per_group = 2.0 * cfg.D * cfg.De + (2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0)               # xproj
+    return 1.0 - (head - per_group / Ae) / cfg.mlp_flops_per_row()
+
+
+def roofline_dict(cfg, prof, dt=None, folded=True, kernel="qinco::mlp_kernel (+ its xproj pre-GEMM)"):
+    launches, avg_ms, fpl, ach = mlp_roofline(prof)
+    ex = executed_share(cfg, cfg.A or cfg.K) if folded else 1.0
+    d = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "frac_executed": ach * ex / PEAK_FP32_MFMA_TFLOPS,
+         "mfma_flops_executed_frac": ex, "mfma_pipe_tflops": ach * ex, "avg_launch_ms": avg_ms,
+         "launches": prof["mlp_launches"], "flops_per_launch": fpl}
+    if dt:
+        d["mlp_share_of_step_time"] = prof["mlp_ms"] * 1e-3 / dt
+    return d
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# extra legs (N = 1, after the timed region)
+# ------------------------------------------------------------------------------------------------------------------
+def leg_workload(torch, dev, name, steps, batch, oracle_sample=0):
+    """One of BASELINE.json's other configurations at its bench batch: K distinct resident batches, timed like the headline,
+    with the fused-MLP roofline.  oracle_sample > 0 (C1): that many vectors are also encoded by the oracle on the host --
+    the count of identical code rows (the north_star's "bit-exact greedy codes") and the oracle's rate on the sample."""
+    from qinco_amd import QincoEngine, synth_state_dict
+    from qinco_amd.config import BASELINE_CONFIGS
+    cfg = BASELINE_CONFIGS[name]
+    sd = synth_state_dict(cfg, 1236)
+    eng = QincoEngine(cfg, sd, max_batch=batch)
+    mean_t = torch.from_numpy(np.asarray(sd["data_mean"])).to(dev)
+    std = float(sd["data_std"])
+    xs = [synth_batch_device(torch, cfg, mean_t, std, batch, 7_000_003 * s + 11, dev) for s in range(steps + 1)]
+    eng.encode(xs[0], code_dtype=np.uint8)
+    torch.cuda.synchronize(dev)
+    eng.profile_enable(True)
+    eng.profile_read()
+    t0 = time.perf_counter()
+    codes = [eng.encode(xs[1 + s], code_dtype=np.uint8) for s in range(steps)]
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    out = {"workload": WORKLOAD_NAMES[name], "value": steps * batch / dt, "unit": "vectors/s", "steps": steps,
+           "vectors_per_step": batch, "ms_per_step": dt / steps * 1e3, "A": cfg.A, "B": cfg.B, "M": cfg.M, "D": cfg.D,
+           "gflop_per_vector": eng.flops_per_vector("encode") / 1e9,
+           "roofline": roofline_dict(cfg, prof, dt, kernel="qinco::mlp_kernel (+ xproj)" if cfg.De <= 384 else "qinco::mlp16_kernel")}
+    if oracle_sample:
+        from oracle.qinco_oracle import OracleQINCo
+        threads = cpu_threads(torch)
+        oracle = OracleQINCo.from_config(cfg, sd, backend="torch")
+        x = xs[1][:oracle_sample].cpu().numpy()
+        got = codes[0][:oracle_sample].cpu().numpy().astype(np.int64)
+        oracle(x[:16], step="encode")
+        t1 = time.perf_counter()
+        want = oracle(x, step="encode").T
+        dt_o = time.perf_counter() - t1
+        same = int((got == want).all(axis=1).sum())
+        out["greedy_rows_equal_to_oracle"] = f"{same}/{oracle_sample}"
+        out["cpu_baseline"] = {"value": oracle_sample / dt_o, "unit": "vectors/s", "cores": threads, "kind": "port",
+                               "gflops": oracle_sample / dt_o * cfg.encode_flops_per_vector() / 1e9,
+                               "sample": f"the same {oracle_sample} vectors in one oracle call ({dt_o:.1f} s, {threads} ATen threads)"}
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    eng.close()
+    del xs, codes
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_encode_db_bvecs(torch, dev, n_db, batch):
+    """`task=encode` end to end (search_tasks.py:85-137): BigANN-style uint8 .bvecs on disk -> memmap (strided rows) ->
+    encode_database(QINCoHIP) in host batches (qinco_encode_host: H2D of the bytes, uint8 -> fp32 and normalisation on the
+    GPU, D2H of the codes) -> `<out>.npz` + part file.  Model: the C2 network with BigANN-magnitude normalisation constants
+    (qinco_amd.synth.apply_regime).  Reported beside the HBM-resident rate of the same model on the same bytes."""
+    from qinco_amd import apply_regime, regime_vectors, synth_state_dict
+    from qinco_amd.config import BASELINE_CONFIGS
+    from qinco_amd.encode_db import EncodedDBIterator, encode_database, get_data_memmap
+    from qinco_amd.model import QINCoHIP
+    cfg = BASELINE_CONFIGS["C2"]
+    sd = apply_regime(cfg, synth_state_dict(cfg, 1236), "bigann", 1236)
+    model = QINCoHIP(cfg, sd, max_batch=batch)
+    block = regime_vectors(cfg, sd, 65536, "bigann", seed=99)           # uint8 (65536, D); the file repeats it with a roll
+    with tempfile.TemporaryDirectory(prefix="qinco_bench_") as tmp:
+        path = os.path.join(tmp, "db.bvecs")
+        rec = np.empty((len(block), cfg.D + 4), np.uint8)
+        rec[:, :4] = np.frombuffer(np.int32(cfg.D).tobytes(), np.uint8)
+        t0 = time.perf_counter()
+        with open(path, "wb") as f:
+            for i in range(0, n_db, len(block)):
+                rec[:, 4:] = np.roll(block, i // len(block), axis=1)   # distinct rows per block
+                f.write(rec[: min(len(block), n_db - i)].tobytes())
+        t_write = time.perf_counter() - t0
+        db = get_data_memmap(path)
+        assert db.shape == (n_db, cfg.D) and db.dtype == np.uint8
+        model(np.ascontiguousarray(db[:batch]), step="encode")        # warm-up (page cache, staging buffers)
+        out_path = os.path.join(tmp, "enc", "db.npz")
+        t0 = time.perf_counter()
+        codes = encode_database(model, db, out_path, K=cfg.K, M=cfg.M, D=cfg.D, batch=4 * batch)
+        dt = time.perf_counter() - t0
+        it = EncodedDBIterator(out_path, K=cfg.K, M=cfg.M, D=cfg.D)
+        part_bytes = os.path.getsize(out_path[:-4] + ".part_0.npz")
+        assert it.n_parts == 1 and codes.shape == (n_db, cfg.M)
+        # the same bytes resident in HBM (device-pointer path)
+        n_res = min(n_db, 8 * batch)
+        xd = torch.from_numpy(np.ascontiguousarray(db[:n_res])).to(dev)
+        model.engine.encode(xd[:batch], code_dtype=np.uint8)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        cres = model.engine.encode(xd, code_dtype=np.uint8)
+        torch.cuda.synchronize(dev)
+        dt_res = time.perf_counter() - t0
+        same = bool(np.array_equal(cres.cpu().numpy().astype(np.int64), codes[:n_res]))
+    model.engine.close()
+    torch.cuda.empty_cache()
+    return {"value": n_db / dt, "unit": "vectors/s", "vectors": n_db, "seconds": dt, "host_batch": 4 * batch,
+            "resident_value": n_res / dt_res, "host_over_resident": (n_db / dt) / (n_res / dt_res),
+            "codes_equal_to_resident_path": same, "input": "uint8 .bvecs",
+            "file_bytes": n_db * (cfg.D + 4), "file_write_s": t_write, "part_file_bytes": part_bytes,
+            "path": "np.memmap (strided uint8 rows) -> encode_database -> QINCoHIP.__call__ -> qinco_encode_host -> np.savez_compressed "
+                    "(includes the int64 part-file compression the reference also does, search_tasks.py:125-131)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,12 +277,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4"])
     ap.add_argument("--batch", type=int, default=16384, help="vectors per step per GPU")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: per-GPU work fixed (K batches per rank); strong: one database split over the ranks")
+    ap.add_argument("--db", type=int, default=0, help="strong scaling: database size (default steps x batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the decode / mse / beam1 / batch_1024 legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the decode / mse / beam1 / batch_1024 / split legs")
+    ap.add_argument("--no-legs", action="store_true", help="skip the c1 / c3 / c4 / encode_db_bvecs legs")
+    ap.add_argument("--bvecs-vectors", type=int, default=1_000_000, help="size of the encode_db_bvecs leg's file")
+    ap.add_argument("--no-affinity", action="store_true", help="do not bind the rank to its GPU's NUMA node")
     ap.add_argument("--split-f16", action="store_true",
                     help="NOT the driver's configuration: run the whole bench (any --gpus) on the opt-in split-fp16 form; the line says so in dtype / config")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (one GPU per rank). gloo is a test hook: ranks may share a GPU.")
+                    help="payload gather: nccl = RCCL over xGMI (one GPU per rank). gloo is a test hook: ranks may share a GPU.")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -153,60 +310,108 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    affinity = None
+    if not args.no_affinity:
+        from qinco_amd.affinity import bind_to_gpu_numa
+        affinity = bind_to_gpu_numa(dev_index)
+
+    # control plane on gloo (always works on one node), payload on RCCL when asked for and available
+    data_group, data_note = None, None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
+            ok = 1
+            try:
+                data_group = dist.new_group(backend="nccl", device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=data_group)      # forces communicator creation now, outside the timed region
+                torch.cuda.synchronize(dev)
+            except Exception as e:                            # noqa: BLE001 -- any failure: part files instead
+                ok, data_note = 0, f"RCCL unavailable on rank {rank}: {type(e).__name__}: {e}"[:300]
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # gloo: everybody agrees on the payload path
+            if int(flag.item()) == 0:
+                data_group = None
+                data_note = data_note or "RCCL unavailable on another rank"
 
     from qinco_amd import QincoEngine, synth_state_dict
     from qinco_amd.config import BASELINE_CONFIGS
+    from qinco_amd.encode_db import shard_bounds
     from qinco_amd.evaluate import sqerr_sum
 
     cfg = BASELINE_CONFIGS[args.workload]
     sd = synth_state_dict(cfg, 1236)
     eng = QincoEngine(cfg, sd, max_batch=args.batch, split_f16=args.split_f16)
     K, W = args.steps, args.warmup
+    strong = args.scaling == "strong"
 
-    # This rank's shard of the synthetic database: step s of rank r encodes rows [(r (W + K) + s) batch, ... + batch) of one
-    # seeded stream; every batch is distinct and resident in HBM before the clock starts.
+    # The synthetic database.  weak: step s of rank r encodes batch (r (W + K) + s) of one seeded stream.  strong: the database
+    # is batches 0 .. ceil(db / batch) - 1 of that stream; rank r owns the reference's contiguous range of it
+    # (search_tasks.py:103-104) and encodes it in passes of `batch` rows.  Everything is resident in HBM before the clock starts.
     mean_t = torch.from_numpy(np.asarray(sd["data_mean"])).to(dev)
     std = float(sd["data_std"])
-    batches = [synth_batch_device(torch, cfg, mean_t, std, args.batch, 1_000_003 * (rank * (W + K) + s) + 42, dev)
-               for s in range(W + K)]
+
+    def stream_batch(i):
+        return synth_batch_device(torch, cfg, mean_t, std, args.batch, 1_000_003 * i + 42, dev)
+
+    warm = [stream_batch(10_000 + rank * max(W, 1) + s) for s in range(W)]
+    if strong:
+        db_size = args.db or K * args.batch
+        start, end = shard_bounds(db_size, world, rank)
+        b0, b1 = start // args.batch, (end + args.batch - 1) // args.batch
+        rows = torch.cat([stream_batch(i) for i in range(b0, b1)])[start - b0 * args.batch: end - b0 * args.batch] \
+            if end > start else torch.empty((0, cfg.D), device=dev)
+        batches = [rows[i:i + args.batch] for i in range(0, len(rows), args.batch)]
+        my_vecs = end - start
+    else:
+        db_size = K * args.batch * world
+        batches = [stream_batch(rank * K + s) for s in range(K)]
+        my_vecs = K * args.batch
 
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
-            if args.backend == "nccl":
-                dist.barrier(device_ids=[dev_index])
-            else:
-                dist.barrier()
+            dist.barrier()                                    # gloo
         torch.cuda.synchronize(dev)
 
-    for s in range(W):
-        eng.encode(batches[s], code_dtype=np.uint8)
+    for xb in warm:
+        eng.encode(xb, code_dtype=np.uint8)
     barrier()
     eng.profile_enable(True)
     eng.profile_read()
-    codes_steps = []
     barrier()
     t0 = time.perf_counter()
-    for s in range(K):
-        codes_steps.append(eng.encode(batches[W + s], code_dtype=np.uint8))
-    mine = torch.stack(codes_steps) if K else torch.empty(0, dtype=torch.uint8, device=dev)
+    codes_steps = [eng.encode(xb, code_dtype=np.uint8) for xb in batches]
+    mine = torch.cat(codes_steps) if codes_steps else torch.empty((0, cfg.M_total), dtype=torch.uint8, device=dev)
     t_enc = t_gather = 0.0
-    if world > 1:  # the end-of-job gather of the uint8 codes over RCCL / xGMI
+    gather_how = None
+    if world > 1:  # the end-of-job gather of the uint8 codes: one collective, shards padded to the longest
         torch.cuda.synchronize(dev)
         t_enc = time.perf_counter() - t0
-        mine_c = mine.to(comm_dev)
-        bucket = [torch.empty_like(mine_c) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine_c, bucket, dst=0)
-        if rank == 0:
-            assert len(bucket) == world and all(b.shape == mine_c.shape for b in bucket)
-        torch.cuda.synchronize(dev)
+        longest = max(shard_bounds(db_size, world, r)[1] - shard_bounds(db_size, world, r)[0] for r in range(world)) if strong \
+            else K * args.batch
+        pad = torch.zeros((longest, cfg.M_total), dtype=torch.uint8, device=dev)
+        pad[: len(mine)] = mine
+        try:
+            if data_group is not None:
+                bucket = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+                dist.gather(pad, bucket, dst=0, group=data_group)
+                torch.cuda.synchronize(dev)
+                gather_how = "rccl"
+            elif args.backend == "gloo":
+                pad_c = pad.cpu()
+                bucket = [torch.empty_like(pad_c) for _ in range(world)] if rank == 0 else None
+                dist.gather(pad_c, bucket, dst=0)
+                gather_how = "gloo (test hook: host buffers)"
+            else:
+                raise RuntimeError(data_note or "no RCCL group")
+            if rank == 0:
+                assert len(bucket) == world and all(b.shape == pad.shape for b in bucket)
+        except Exception as e:                                # noqa: BLE001 -- fail soft: the reference's own part files
+            outdir = os.environ.get("QINCO_BENCH_PARTS", tempfile.gettempdir())
+            np.savez_compressed(os.path.join(outdir, f"qinco_bench_codes.part_{rank}.npz"), codes=mine.cpu().numpy())
+            gather_how = f"failed: {type(e).__name__}: {e}"[:300] + " -> part files"
         t_gather = time.perf_counter() - t0 - t_enc
     barrier()
     dt = time.perf_counter() - t0
@@ -214,169 +419,170 @@ def main():
     eng.profile_enable(False)
 
     per_rank = None
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
+    if world > 1:   # timing exchange on the control plane (gloo, host tensors)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        mine_t = torch.tensor([t_enc, t_gather], dtype=torch.float64, device=comm_dev)
+        mine_t = torch.tensor([t_enc, t_gather, float(my_vecs), 0.0 if (gather_how or "").startswith("failed") else 1.0],
+                              dtype=torch.float64)
         allt = [torch.empty_like(mine_t) for _ in range(world)]
         dist.all_gather(allt, mine_t)
-        per_rank = [[float(a[0]), float(a[1])] for a in allt]
+        per_rank = [[float(v) for v in a] for a in allt]
 
     if rank == 0:
-        total_vecs = K * args.batch * world
+        total_vecs = db_size
         value = total_vecs / dt if dt > 0 else 0.0
         mlp_row = cfg.mlp_flops_per_row()
-
-        def mlp_roofline(pr):
-            launches = max(pr["mlp_launches"], 1)
-            avg_ms = pr["mlp_ms"] / launches
-            fpl = pr["mlp_flops"] / launches
-            ach = fpl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            return launches, avg_ms, fpl, ach
-
-        launches, avg_ms, flops_per_launch, achieved = mlp_roofline(prof)
+        rf = roofline_dict(cfg, prof, dt, kernel=("qinco::mlp_kernel (+ its xproj pre-GEMM)" if not args.split_f16 else
+                                                  "qinco::mlp_split_kernel (+ xproj_split): fp16 pipe, so frac against the fp32-MFMA peak exceeds 1"))
         bpr, bpr_src = pmc_traffic_per_row() if args.workload == "C2" else (None, None)
-        rows_per_launch = flops_per_launch / mlp_row
-        # FOLD / FOLD2 (mlp_kernel.hpp): the row-independent head of the MLP is not recomputed per row, so the MFMA
-        # executes fewer FLOPs than the reference's algorithm counts.
-        def executed_share(Ae):
-            head = (2.0 * cfg.D * cfg.De if cfg.De != cfg.D else 0.0) + 2.0 * (cfg.De + cfg.D) * cfg.De   # FOLD
-            head += 2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0                                            # FOLD2
-            per_group = 2.0 * cfg.D * cfg.De + (2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0)               # xproj
-            return 1.0 - (head - per_group / Ae) / mlp_row
-        executed = executed_share(cfg.A or cfg.K)
+        rows_per_launch = rf["flops_per_launch"] / mlp_row
+        rf["traffic"] = bpr * rows_per_launch if bpr else None
+        rf["traffic_unit"] = f"bytes per launch (L2<->fabric, PMC pass in profiles/{bpr_src})" if bpr else None
         out = {
             "metric": "encode vectors/sec (BigANN-shaped d=128 8x8, beam=%d)" % cfg.B,
             "value": value, "unit": "vectors/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": dt / K * 1e3 if K else 0.0, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / K * 1e3 if K else 0.0, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32" if not args.split_f16 else "f32 operands as fp16 hi+lo on the fp16 MFMA, fp32 accumulate (--split-f16)",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: qinco2-L 8x8 encode" if args.workload == "C2" else args.workload,
+            "config": {"workload": WORKLOAD_NAMES[args.workload],
                        "D": cfg.D, "M": cfg.M, "K": cfg.K, "L": cfg.L, "de": cfg.De, "dh": cfg.dh, "A": cfg.A, "B": cfg.B,
-                       "vectors_per_step_per_gpu": args.batch, "parallelism": f"shard{world}",
-                       "distinct_vectors_encoded": total_vecs,
+                       "vectors_per_step_per_gpu": args.batch if not strong else None,
+                       "parallelism": f"shard{world}", "distinct_vectors_encoded": total_vecs,
                        "inputs": "every step encodes a different seeded batch, all resident in HBM before the clock starts",
                        "weights": "seeded synthetic (RandomState 1236)",
-                       "gflop_per_vector": eng.flops_per_vector("encode") / 1e9},
-            "roofline": {"bound": "mfma", "kernel": ("qinco::mlp_kernel (+ its xproj pre-GEMM)" if not args.split_f16 else
-                                                      "qinco::mlp_split_kernel (+ xproj_split): fp16 pipe, so frac against the fp32-MFMA peak exceeds 1"),
-                         "achieved": achieved,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "frac_executed": achieved * executed / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": (bpr * rows_per_launch if bpr else None),
-                         "traffic_unit": f"bytes per launch (L2<->fabric, PMC pass in profiles/{bpr_src})" if bpr else None,
-                         "mfma_flops_executed_frac": executed, "mfma_pipe_tflops": achieved * executed,
-                         "avg_launch_ms": avg_ms, "launches": prof["mlp_launches"],
-                         "flops_per_launch": flops_per_launch,
-                         "mlp_share_of_step_time": prof["mlp_ms"] * 1e-3 / dt if dt > 0 else None},
+                       "gflop_per_vector": eng.flops_per_vector("encode") / 1e9,
+                       "kernel_instances": eng.describe(), "cpu_affinity": affinity},
+            "roofline": rf,
         }
         if world > 1:
             out["multi_gpu"] = {
-                "backend": args.backend,
-                "per_rank_encode_vectors_per_s": [K * args.batch / t[0] if t[0] > 0 else 0.0 for t in per_rank],
+                "backend": args.backend, "control_plane": "gloo", "gather": gather_how,
+                "gather_ok_on_all_ranks": all(t[3] == 1.0 for t in per_rank),
+                "rccl_note": data_note,
+                "per_rank_vectors": [int(t[2]) for t in per_rank],
+                "per_rank_encode_vectors_per_s": [t[2] / t[0] if t[0] > 0 else 0.0 for t in per_rank],
                 "per_rank_encode_s": [t[0] for t in per_rank],
                 "per_rank_gather_s": [t[1] for t in per_rank],
-                "gather_bytes_per_rank": int(mine.numel()),
+                "gather_bytes_per_rank": int(longest * cfg.M_total),
                 "note": "gather time of a rank includes waiting for the slowest rank's encode",
             }
-        if world == 1 and not args.no_extras and K > 0:
-            # ---- decode of the codes just produced + MSE of encode -> decode (qinco_tasks.py:87-148) ----
-            codes_all = mine.reshape(-1, cfg.M_total)
-            eng.decode(codes_all[:args.batch], check=False)
-            torch.cuda.synchronize(dev)
-            eng.profile_enable(True)
-            eng.profile_read()
-            t1 = time.perf_counter()
-            dec = eng.decode(codes_all, check=False)
-            torch.cuda.synchronize(dev)
-            dt_dec = time.perf_counter() - t1
-            prd = eng.profile_read()
-            eng.profile_enable(False)
-            eng.check_codes()
-            _, d_ms, _, d_ach = mlp_roofline(prd)
-            d_exec = executed_share(1)
-            out["decode"] = {"value": codes_all.shape[0] / dt_dec, "unit": "vectors/s", "vectors": int(codes_all.shape[0]),
-                             "gflop_per_vector": eng.flops_per_vector("decode") / 1e9,
-                             "roofline": {"bound": "mfma", "achieved": d_ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                          "frac": d_ach / PEAK_FP32_MFMA_TFLOPS,
-                                          "frac_executed": d_ach * d_exec / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": d_ms}}
-            xs = torch.cat(batches[W:W + K])
-            out["mse"] = {"value": sqerr_sum(xs, dec) / xs.shape[0], "vectors": int(xs.shape[0]),
-                          "definition": "sum_i |x_i - decode(encode(x_i))|^2 / N (mse_scale 1; metrics.py:51-58)"}
-            del dec, xs
-
-            def timed_encode(xb_list):
-                for xb in xb_list[:1]:
-                    eng.encode(xb, code_dtype=np.uint8)
-                torch.cuda.synchronize(dev)
-                t2 = time.perf_counter()
-                for xb in xb_list:
-                    eng.encode(xb, code_dtype=np.uint8)
-                torch.cuda.synchronize(dev)
-                return sum(len(xb) for xb in xb_list) / (time.perf_counter() - t2)
-            # ---- the reference's default host batch (qinco_cfg.yaml:38): 1024 vectors per call ----
-            small = [batches[W][i:i + 1024] for i in range(0, min(args.batch, 16384), 1024)]
-            out["batch_1024"] = {"value": timed_encode(small), "unit": "vectors/s", "calls": len(small),
-                                 "note": "same engine, one encode call per 1024 distinct vectors"}
-            # ---- greedy search (beam = 1, BASELINE metric: beam in {1, 8}) ----
-            if cfg.B > 1:
-                eng.set_beam(B=1)
-                out["beam1"] = {"value": timed_encode(batches[W:W + min(K, 2)]), "unit": "vectors/s", "A": eng.A, "B": 1,
-                                "gflop_per_vector": eng.flops_per_vector("encode") / 1e9}
-                eng.set_beam(B=cfg.B)
-            # ---- the opt-in split-fp16 form of the FFN blocks (include/qinco_hip.h QINCO_CREATE_SPLIT_F16): NOT the headline --
-            # `value` above is the fp32 path; this leg re-encodes the same timed batches and counts the code rows that change
-            try:
-                if args.split_f16:
-                    raise RuntimeError("the whole line is the split form (--split-f16); roofline.frac is quoted against the fp32-MFMA peak")
-                eng2 = QincoEngine(cfg, sd, max_batch=args.batch, split_f16=True)
-            except Exception as e:      # no split instance for this shape (or any other failure): the headline must not depend on it
-                eng2 = None
-                out["split_f16"] = {"error": f"{type(e).__name__}: {e}"}
-            if eng2 is not None:
-                try:
-                    eng2.encode(batches[0], code_dtype=np.uint8)
-                    torch.cuda.synchronize(dev)
-                    eng2.profile_enable(True)
-                    eng2.profile_read()
-                    t3 = time.perf_counter()
-                    codes2 = torch.stack([eng2.encode(batches[W + s], code_dtype=np.uint8) for s in range(K)])
-                    torch.cuda.synchronize(dev)
-                    dt2 = time.perf_counter() - t3
-                    pr2 = eng2.profile_read()
-                    eng2.profile_enable(False)
-                    _, s_ms, s_fpl, s_ach = mlp_roofline(pr2)
-                    differ = int((codes2.reshape(-1, cfg.M_total) != codes_all).any(dim=1).sum().item())
-                    dec2 = eng2.decode(codes2.reshape(-1, cfg.M_total), check=False)
-                    xs = torch.cat(batches[W:W + K])
-                    blocks = 4.0 * cfg.L * cfg.De * cfg.dh - 2.0 * cfg.De * cfg.dh          # per row, block 0's up-projection folded
-                    if cfg.De != cfg.D and (cfg.D // 32) % 2 == 0:
-                        blocks += 2.0 * cfg.D * cfg.De                                      # out_proj in the split form too
-                    blocks += (2.0 * cfg.D * cfg.De + 2.0 * cfg.De * cfg.dh) / (cfg.A or cfg.K)   # xproj, per group
-                    f16_tflops = 3.0 * blocks * (s_fpl / mlp_row) / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
-                    out["split_f16"] = {
-                        "value": K * args.batch / dt2, "unit": "vectors/s", "ms_per_step": dt2 / K * 1e3,
-                        "speedup_vs_f32_path": (K * args.batch / dt2) / value if value > 0 else None,
-                        "rows_differing_from_f32_path": differ, "rows": int(codes_all.shape[0]),
-                        "mse": sqerr_sum(xs, dec2) / xs.shape[0],
-                        "roofline": {"bound": "mfma", "kernel": "qinco::mlp_split_kernel (+ xproj)", "avg_launch_ms": s_ms,
-                                     "achieved_algorithmic_fp32_equivalent_tflops": s_ach,
-                                     "f16_mfma_tflops_executed": f16_tflops, "peak_f16_mfma_tflops": PEAK_F16_MFMA_TFLOPS,
-                                     "frac_of_f16_peak": f16_tflops / PEAK_F16_MFMA_TFLOPS},
-                        "arithmetic": "FFN blocks, out_proj, xproj: fp32 operands as fp16 hi + lo, 3 fp16 MFMAs per product, fp32 accumulate; tables, distances, selection fp32",
-                        "note": "opt-in (QincoEngine(split_f16=True) / qinco_create_ex); parity tests: tests/test_hip_parity.py::test_split_f16_*"}
-                    del dec2, xs, codes2
-                    eng2.close()
-                except Exception as e:
-                    out["split_f16"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_extras and K > 0 and not strong:
+            extras(torch, dev, args, cfg, sd, eng, out, mine, batches, warm, value, sqerr_sum, QincoEngine)
+        if world == 1 and not args.no_legs and not args.split_f16:
+            for key, fn in (("c1", lambda: leg_workload(torch, dev, "C1", 3, 16384, oracle_sample=256)),
+                            ("c3", lambda: leg_workload(torch, dev, "C3", 2, 16384)),
+                            ("c4", lambda: leg_workload(torch, dev, "C4", 2, 16384)),
+                            ("encode_db_bvecs", lambda: leg_encode_db_bvecs(torch, dev, args.bvecs_vectors, 16384))):
+                try:        # a leg can never take the headline down with it
+                    out[key] = fn()
+                except Exception as e:                        # noqa: BLE001
+                    out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(torch, dev, args, cfg, sd, eng, out, mine, batches, warm, value, sqerr_sum, QincoEngine):
+    """decode / mse / batch_1024 / beam1 / split_f16 on the timed batches (N = 1)."""
+    K = len(batches)
+    mlp_row = cfg.mlp_flops_per_row()
+    # ---- decode of the codes just produced + MSE of encode -> decode (qinco_tasks.py:87-148) ----
+    codes_all = mine.reshape(-1, cfg.M_total)
+    eng.decode(codes_all[:args.batch], check=False)
+    torch.cuda.synchronize(dev)
+    eng.profile_enable(True)
+    eng.profile_read()
+    t1 = time.perf_counter()
+    dec = eng.decode(codes_all, check=False)
+    torch.cuda.synchronize(dev)
+    dt_dec = time.perf_counter() - t1
+    prd = eng.profile_read()
+    eng.profile_enable(False)
+    eng.check_codes()
+    _, d_ms, _, d_ach = mlp_roofline(prd)
+    # decode runs the shape's un-folded instance when it has one (csrc/shapes.def), else the folded encode instance
+    d_exec = 1.0 if "decode_var=-1" not in eng.describe() and not args.split_f16 else executed_share(cfg, 1)
+    out["decode"] = {"value": codes_all.shape[0] / dt_dec, "unit": "vectors/s", "vectors": int(codes_all.shape[0]),
+                     "gflop_per_vector": eng.flops_per_vector("decode") / 1e9,
+                     "roofline": {"bound": "mfma", "achieved": d_ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": d_ach / PEAK_FP32_MFMA_TFLOPS,
+                                  "frac_executed": d_ach * d_exec / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": d_ms}}
+    xs = torch.cat(batches)
+    out["mse"] = {"value": sqerr_sum(xs, dec) / xs.shape[0], "vectors": int(xs.shape[0]),
+                  "definition": "sum_i |x_i - decode(encode(x_i))|^2 / N (mse_scale 1; metrics.py:51-58)"}
+    del dec, xs
+
+    def timed_encode(xb_list):
+        for xb in xb_list[:1]:
+            eng.encode(xb, code_dtype=np.uint8)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for xb in xb_list:
+            eng.encode(xb, code_dtype=np.uint8)
+        torch.cuda.synchronize(dev)
+        return sum(len(xb) for xb in xb_list) / (time.perf_counter() - t2)
+    # ---- the reference's default host batch (qinco_cfg.yaml:38): 1024 vectors per call ----
+    small = [batches[0][i:i + 1024] for i in range(0, min(args.batch, 16384), 1024)]
+    out["batch_1024"] = {"value": timed_encode(small), "unit": "vectors/s", "calls": len(small),
+                         "note": "same engine, one encode call per 1024 distinct vectors"}
+    # ---- greedy search (beam = 1, BASELINE metric: beam in {1, 8}) ----
+    if cfg.B > 1:
+        eng.set_beam(B=1)
+        out["beam1"] = {"value": timed_encode(batches[:min(K, 2)]), "unit": "vectors/s", "A": eng.A, "B": 1,
+                        "gflop_per_vector": eng.flops_per_vector("encode") / 1e9}
+        eng.set_beam(B=cfg.B)
+    # ---- the opt-in split-fp16 form of the FFN blocks (include/qinco_hip.h QINCO_CREATE_SPLIT_F16): NOT the headline --
+    # `value` above is the fp32 path; this leg re-encodes the same timed batches and counts the code rows that change
+    try:
+        if args.split_f16:
+            raise RuntimeError("the whole line is the split form (--split-f16); roofline.frac is quoted against the fp32-MFMA peak")
+        eng2 = QincoEngine(cfg, sd, max_batch=args.batch, split_f16=True)
+    except Exception as e:      # no split instance for this shape (or any other failure): the headline must not depend on it
+        out["split_f16"] = {"error": f"{type(e).__name__}: {e}"}
+        return
+    try:
+        eng2.encode(warm[0] if warm else batches[0], code_dtype=np.uint8)
+        torch.cuda.synchronize(dev)
+        eng2.profile_enable(True)
+        eng2.profile_read()
+        t3 = time.perf_counter()
+        codes2 = torch.cat([eng2.encode(xb, code_dtype=np.uint8) for xb in batches])
+        torch.cuda.synchronize(dev)
+        dt2 = time.perf_counter() - t3
+        pr2 = eng2.profile_read()
+        eng2.profile_enable(False)
+        _, s_ms, s_fpl, s_ach = mlp_roofline(pr2)
+        differ = int((codes2 != codes_all).any(dim=1).sum().item())
+        dec2 = eng2.decode(codes2, check=False)
+        xs = torch.cat(batches)
+        blocks = 4.0 * cfg.L * cfg.De * cfg.dh - 2.0 * cfg.De * cfg.dh          # per row, block 0's up-projection folded
+        if cfg.De != cfg.D and (cfg.D // 32) % 2 == 0:
+            blocks += 2.0 * cfg.D * cfg.De                                      # out_proj in the split form too
+        blocks += (2.0 * cfg.D * cfg.De + 2.0 * cfg.De * cfg.dh) / (cfg.A or cfg.K)   # xproj, per group
+        f16_tflops = 3.0 * blocks * (s_fpl / mlp_row) / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
+        n_all = int(codes_all.shape[0])
+        out["split_f16"] = {
+            "value": n_all / dt2, "unit": "vectors/s", "ms_per_step": dt2 / K * 1e3,
+            "speedup_vs_f32_path": (n_all / dt2) / value if value > 0 else None,
+            "rows_differing_from_f32_path": differ, "rows": n_all,
+            "mse": sqerr_sum(xs, dec2) / xs.shape[0],
+            "roofline": {"bound": "mfma", "kernel": "qinco::mlp_split_kernel (+ xproj)", "avg_launch_ms": s_ms,
+                         "achieved_algorithmic_fp32_equivalent_tflops": s_ach,
+                         "f16_mfma_tflops_executed": f16_tflops, "peak_f16_mfma_tflops": PEAK_F16_MFMA_TFLOPS,
+                         "frac_of_f16_peak": f16_tflops / PEAK_F16_MFMA_TFLOPS},
+            "arithmetic": "FFN blocks, out_proj, xproj: fp32 operands as fp16 hi + lo, 3 fp16 MFMAs per product, fp32 accumulate; tables, distances, selection fp32",
+            "note": "opt-in (QincoEngine(split_f16=True) / qinco_create_ex); parity tests: tests/test_hip_parity.py::test_split_f16_*"}
+        del dec2, xs, codes2
+        eng2.close()
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["split_f16"] = {"error": f"{type(e).__name__}: {e}"}
 
 
 if __name__ == "__main__":

@@ -87,11 +87,32 @@ QINCO_API int qinco_create(const qinco_desc* desc, const qinco_weights* weights,
  * FLOPs of qinco2-L) on the fp16 matrix pipe with every fp32 operand split into two fp16 values (hi + lo, three MFMAs per
  * product, fp32 accumulation; csrc/mlp_split_kernel.hpp) instead of the fp32-in MFMA, which runs at 1/16 of the fp16 rate on
  * gfx950.  Same function and an error of the same class as the fp32 path against a float64 evaluation, but not the
- * same bits: opt-in, off by default; QINCO_ERR_UNSUPPORTED if the shape has no split instance (csrc/shapes.def) or L == 0.
+ * same bits: opt-in, off by default; QINCO_ERR_UNSUPPORTED if the shape has no split instance (csrc/shapes.def).
  * fp16 has a range: activations beyond |z| ~ 8000 (never seen with std-normalised data) overflow; the kernel then raises the
- * sticky device flag and qinco_encode_host / qinco_check return QINCO_ERR_RANGE instead of codes selected from NaNs. */
-enum { QINCO_CREATE_SPLIT_F16 = 1 };
+ * sticky device flag and qinco_encode_host / qinco_decode_host / qinco_check return QINCO_ERR_RANGE instead of results computed
+ * from NaNs.  The library reads NO environment variables: every switch is an argument.
+ * The other flags are diagnostics (A/B measurements, the race-detector tests): the exact fp32 IVF table without the fp16
+ * filter; the VALU pre-selection table; decode through the folded encode instance; no cooperative table kernel. */
+enum {
+  QINCO_CREATE_SPLIT_F16 = 1,
+  QINCO_CREATE_IVF_FP32 = 2,
+  QINCO_CREATE_TABLE_VALU = 4,
+  QINCO_CREATE_DECODE_FOLDED = 8,
+  QINCO_CREATE_TABLE_NO_COOP = 16
+};
 QINCO_API int qinco_create_ex(const qinco_desc* desc, const qinco_weights* weights, int32_t create_flags, qinco_handle* out);
+
+/* ... and with the remaining diagnostic knobs.  struct_bytes = sizeof(qinco_options) (lets the struct grow); mlp_P / mlp_var
+ * select a non-production fused-MLP kernel instance of the model's shape (csrc/shapes.def: QINCO_SHAPE(D, De, Dh, P, VAR)),
+ * -1 / -1 = the production instance; table_coop_max = largest launch (in groups) that takes the cooperative pre-selection
+ * kernel, -1 = default.  opt == NULL is qinco_create. */
+typedef struct {
+  int32_t struct_bytes;
+  int32_t create_flags;
+  int32_t mlp_P, mlp_var;
+  int64_t table_coop_max;
+} qinco_options;
+QINCO_API int qinco_create_opt(const qinco_desc* desc, const qinco_weights* weights, const qinco_options* opt, qinco_handle* out);
 QINCO_API int qinco_destroy(qinco_handle h);
 
 /* Change the search width.  A must be 0 iff the model was created with A == 0 (utils.py:169-172); 0 < A <= K. */
@@ -132,6 +153,11 @@ QINCO_API double qinco_flops_per_vector_decode(qinco_handle h);
  * kernel had to redo the batch (candidate list full, or inputs outside the fp16 range).  Both 0 when the handle has no
  * fp16 copy (QINCO_IVF_FP32=1, or centroids outside the fp16 range).  Synchronises the device. */
 QINCO_API int qinco_ivf_last_stats(qinco_handle h, int64_t* candidates, int32_t* fell_back);
+
+/* One line about the handle for logs and bench records: the fused-MLP kernel instance serving encode ("mlp=DxDexDh P=.. var=..",
+ * csrc/shapes.def), the instance serving decode (decode_var=-1: the encode instance), the arithmetic form, the table kernels.
+ * Writes at most `cap` bytes including the terminator; returns the length the full text needs. */
+QINCO_API int qinco_describe(qinco_handle h, char* buf, int32_t cap);
 
 /* 1 if a fused-MLP kernel instance exists for (D, De, Dh). */
 QINCO_API int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh);

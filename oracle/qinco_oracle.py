@@ -127,6 +127,7 @@ class OracleQINCo:
         assert self.data_std > 0, "data_std must be > 0 (qinco_base.py:526)"
         self.steps = [StepWeights(self.sd, m, L) for m in range(M)]
         self.D = self.steps[0].codebook.shape[1]
+        self._prefer, self._tie = None, F32(0)
         if A > 0 and M > 1 and self.steps[1].sub_codebook is None:
             raise ValueError("Can't evaluate a model trained with A=0 (no candidates pre-selection) "
                              "using a non-zero A value.")  # utils.py:169-172
@@ -148,12 +149,19 @@ class OracleQINCo:
         return xhat * self.data_std + self.data_mean
 
     # ---- encode (QINCoInferenceEncoder.forward qinco_inference.py:239-254) -----------------------
-    def encode(self, x: np.ndarray, trace: dict | None = None):
+    def encode(self, x: np.ndarray, trace: dict | None = None, prefer: np.ndarray | None = None, tie: float = 2e-5):
+        """prefer (test diagnostics only; None = the reference algorithm): (n, M) code rows.  Every selection then favours the
+        candidates that lie on the preferred row's path by a relative `tie` of their distance -- a rounding-level
+        perturbation.  If the result equals `prefer`, that row is an outcome the reference algorithm itself reaches when
+        its near-ties fall the other way; this is how the tests decide whether a differing GPU row is legitimate."""
         n, D = x.shape
         M, K, A, B = self.M, self.K, self.A, self.B
+        self._prefer, self._tie = (None if prefer is None else np.asarray(prefer).T), F32(tie)   # (M, n)
         K0 = self.steps[0].codebook.shape[0]
         beam_0 = 1 if (M == 1 or self.ivf) else min(B, K0)  # :237; a one-step model must end with one beam
         d0 = approx_pairwise_distance(x, self.steps[0].codebook)
+        if self._prefer is not None:
+            d0 = self._favour(d0, np.arange(K0)[None, :] == self._prefer[0][:, None])
         codes0 = topk_smallest(d0, beam_0)  # argmin when beam_0 == 1 (:243-245)
         xhat = self.steps[0].codebook[codes0]  # (n, F, D)
         codes = codes0[None]  # (1, n, F)
@@ -169,18 +177,32 @@ class OracleQINCo:
                 xhat, codes = self._step_all(self.steps[m], x, xhat, codes, F_out, trace, m)
         return codes[:, :, 0].astype(np.int64), xhat[:, 0, :]
 
+    def _favour(self, d, mask):
+        return np.where(mask, d - self._tie * np.abs(d), d).astype(F32)
+
+    def _on_path(self, codes):
+        """(n, F): beams whose code history equals the preferred row's prefix."""
+        return (codes == self._prefer[: codes.shape[0], :, None]).all(axis=0)
+
     def _step_preselect(self, w, x, xhat, codes, A, F_out, trace, m):
         """QINCoInferenceStepEncoder.forward (qinco_inference.py:156-224)."""
         n, F, D = xhat.shape
         Mc = codes.shape[0]
         xtarget = x[:, None, :] - xhat  # :171
         d_sub = approx_pairwise_distance(xtarget.reshape(n * F, D), w.sub_codebook)  # :172
+        if self._prefer is not None:
+            want = np.repeat(self._prefer[m], F)
+            d_sub = self._favour(d_sub, self._on_path(codes).reshape(n * F, 1) & (np.arange(d_sub.shape[1])[None, :] == want[:, None]))
         top = topk_smallest(d_sub, A)  # (n*F, A) :173
         cw = w.codebook[top].reshape(n, F, A, D)  # :175
         out = self._mlp(w, cw, xhat[:, :, None, :], self.qinco1_mode)  # :178-188
         cand = out + xhat[:, :, None, :]  # :190-191
         cand_flat = cand.reshape(n, F * A, D)
         dists = approx_compute_batch_distances(x[:, None, :], cand_flat)  # :194-199
+        dists_ref = dists
+        if self._prefer is not None:
+            sel = self._on_path(codes)[:, :, None] & (top.reshape(n, F, A) == self._prefer[m][:, None, None])
+            dists = self._favour(dists, sel.reshape(n, F * A))
         F_out = min(F_out, F * A)
         idx = topk_smallest(dists, F_out)  # (n, F_out) :200
         real = np.take_along_axis(top.reshape(n, F * A), idx, axis=-1)  # :203-204
@@ -190,7 +212,7 @@ class OracleQINCo:
         if trace is not None:
             trace[f"top{m}"] = top.reshape(n, F, A)
             trace[f"dsub{m}"] = d_sub.reshape(n, F, -1)
-            trace[f"dists{m}"] = dists
+            trace[f"dists{m}"] = dists_ref
         return xnext, np.concatenate([hist, real[None]], axis=0)  # :222
 
     def _step_all(self, w, x, xhat, codes, F_out, trace, m):
@@ -205,6 +227,10 @@ class OracleQINCo:
         cand = out + xhat[:, :, None, :]
         cand_flat = cand.reshape(n, F * K, D)
         dists = approx_compute_batch_distances(x[:, None, :], cand_flat)
+        dists_ref = dists
+        if self._prefer is not None:
+            sel = self._on_path(codes)[:, :, None] & (np.arange(K)[None, None, :] == self._prefer[m][:, None, None])
+            dists = self._favour(dists, sel.reshape(n, F * K))
         F_out = min(F_out, F * K)
         idx = topk_smallest(dists, F_out)
         real = idx % K
@@ -212,7 +238,7 @@ class OracleQINCo:
         hist = np.take_along_axis(hist, np.broadcast_to(idx[None], (Mc, n, F_out)), axis=-1)
         xnext = np.take_along_axis(cand_flat, idx[:, :, None], axis=1)
         if trace is not None:
-            trace[f"dists{m}"] = dists
+            trace[f"dists{m}"] = dists_ref
         return xnext, np.concatenate([hist, real[None]], axis=0)
 
     # ---- decode (QINCoInferenceDecoder.forward qinco_inference.py:66-75) --------------------------

@@ -11,11 +11,11 @@ LIB_PATH = PKG / "libqinco_hip.so"
 X_F32, X_U8 = 0, 1
 CODE_I64, CODE_I32, CODE_U8 = 0, 1, 2
 FLAG_NORMALISED = 1
-CREATE_SPLIT_F16 = 1
+CREATE_SPLIT_F16, CREATE_IVF_FP32, CREATE_TABLE_VALU, CREATE_DECODE_FOLDED, CREATE_TABLE_NO_COOP = 1, 2, 4, 8, 16
 
 # every symbol include/qinco_hip.h declares (tests check the library exports all of them)
 API_SYMBOLS = [
-    "qinco_create", "qinco_create_ex", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
+    "qinco_create", "qinco_create_ex", "qinco_create_opt", "qinco_describe", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
     "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
     "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
@@ -27,6 +27,11 @@ class QincoDesc(C.Structure):
     _fields_ = [("D", C.c_int32), ("De", C.c_int32), ("Dh", C.c_int32), ("L", C.c_int32), ("M", C.c_int32),
                 ("K", C.c_int32), ("A", C.c_int32), ("B", C.c_int32), ("qinco1_mode", C.c_int32),
                 ("ivf_K", C.c_int32), ("max_batch", C.c_int64)]
+
+
+class QincoOptions(C.Structure):
+    _fields_ = [("struct_bytes", C.c_int32), ("create_flags", C.c_int32), ("mlp_P", C.c_int32), ("mlp_var", C.c_int32),
+                ("table_coop_max", C.c_int64)]
 
 
 FP = C.POINTER(C.c_float)
@@ -87,6 +92,10 @@ def load() -> C.CDLL:
     vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
     lib.qinco_create.argtypes = [C.POINTER(QincoDesc), C.POINTER(QincoWeights), C.POINTER(vp)]
     lib.qinco_create_ex.argtypes = [C.POINTER(QincoDesc), C.POINTER(QincoWeights), C.c_int32, C.POINTER(vp)]
+    lib.qinco_create_opt.argtypes = [C.POINTER(QincoDesc), C.POINTER(QincoWeights), C.POINTER(QincoOptions), C.POINTER(vp)]
+    lib.qinco_create_opt.restype = C.c_int
+    lib.qinco_describe.argtypes = [vp, C.c_char_p, C.c_int32]
+    lib.qinco_describe.restype = C.c_int
     lib.qinco_destroy.argtypes = [vp]
     lib.qinco_set_beam.argtypes = [vp, C.c_int32, C.c_int32]
     lib.qinco_encode.argtypes = [vp, vp, i32, i64, i64, vp, i32, vp, i32, vp]

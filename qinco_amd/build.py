@@ -36,11 +36,25 @@ def hipcc() -> str:
     return exe
 
 
-def _newer(target: Path, deps: list[Path]) -> bool:
-    if not target.exists():
+def _deps_of(obj: Path) -> list[Path] | None:
+    """Prerequisites hipcc recorded for `obj` (-MD -MF obj.d: every file the translation unit really included)."""
+    d = obj.with_suffix(".d")
+    if not d.exists():
+        return None
+    txt = d.read_text().replace("\\\n", " ")
+    body = txt.split(":", 1)[1] if ":" in txt else ""
+    root = str(PKG.parent)   # (toolchain / system headers are not tracked)
+    return [Path(t) for t in body.split() if t.startswith(root) and not t.endswith(":")]
+
+
+def _fresh(obj: Path, cmd: list[str]) -> bool:
+    """obj exists, is newer than every recorded prerequisite, and was built by the same command line."""
+    deps = _deps_of(obj)
+    stamp = obj.with_suffix(".cmd")
+    if not obj.exists() or deps is None or not stamp.exists() or stamp.read_text() != " ".join(cmd):
         return False
-    t = target.stat().st_mtime
-    return all(d.stat().st_mtime <= t for d in deps)
+    t = obj.stat().st_mtime
+    return all(d.exists() and d.stat().st_mtime <= t for d in deps)
 
 
 def _run(cmd: list[str]) -> None:
@@ -49,42 +63,51 @@ def _run(cmd: list[str]) -> None:
         raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
 
 
+def _compile(obj: Path, cmd: list[str]) -> None:
+    _run([*cmd, "-MD", "-MF", str(obj.with_suffix(".d"))])
+    obj.with_suffix(".cmd").write_text(" ".join(cmd))
+
+
+def instance_cmd(cc: str, shape: tuple, out: Path, extra: tuple = ()) -> list[str]:
+    d, de, dh, p, var = shape
+    return [cc, *FLAGS, *extra, f"-DQD={d}", f"-DQDE={de}", f"-DQDH={dh}", f"-DQP={p}", f"-DQVAR={var}", "-c",
+            str(CSRC / "mlp_inst.hip"), "-o", str(out)]
+
+
 def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> Path:
+    """Incremental: an object is rebuilt when its command line changed or any file it included (hipcc -MD depfile) is newer."""
     OBJ.mkdir(exist_ok=True)
     cc = hipcc()
-    mlp_deps = [CSRC / n for n in ("mlp_kernel.hpp", "mlp16_kernel.hpp", "mlp_split_kernel.hpp", "mlp_args.hpp", "mlp_launch.hpp", "mlp_inst.hip")]
-    headers = sorted(CSRC.glob("*.hpp")) + [CSRC / "shapes.def", PKG.parent / "include" / "qinco_hip.h"]
     tasks: list[tuple[Path, list[str]]] = []
     objs: list[Path] = []
-    for (d, de, dh, p, var) in shapes():
-        o = OBJ / f"mlp_{d}_{de}_{dh}_{p}_{var}.o"
+
+    def want(o: Path, cmd: list[str]):
         objs.append(o)
-        if force or not _newer(o, mlp_deps):
-            tasks.append((o, [cc, *FLAGS, f"-DQD={d}", f"-DQDE={de}", f"-DQDH={dh}", f"-DQP={p}", f"-DQVAR={var}", "-c",
-                              str(CSRC / "mlp_inst.hip"), "-o", str(o)]))
+        if force or not _fresh(o, cmd):
+            tasks.append((o, cmd))
+
+    for shape in shapes():
+        o = OBJ / ("mlp_" + "_".join(map(str, shape)) + ".o")
+        want(o, instance_cmd(cc, shape, o))
+    # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs.  The table / filter kernels post-process every accumulator on the VALU
+    # (arg-min, max, compare), which cannot read AGPRs: with AGPR accumulators the IVF filter spent 3 of 4 VALU instructions
+    # on v_accvgpr_read / write (csrc/ivf_f16_kernel.hpp).  The fused-MLP instances are separate objects and keep their plan.
     o = OBJ / "qinco_hip.o"
-    objs.append(o)
-    if force or not _newer(o, headers + [CSRC / "qinco_hip.hip"]):
-        # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs.  The table / filter kernels post-process every accumulator on the VALU
-        # (arg-min, max, compare), which cannot read AGPRs: with AGPR accumulators the IVF filter spent 3 of 4 VALU instructions
-        # on v_accvgpr_read / write (csrc/ivf_f16_kernel.hpp).  The fused-MLP instances are separate objects and keep their plan.
-        tasks.append((o, [cc, *FLAGS, "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", str(CSRC / "qinco_hip.hip"), "-o", str(o)]))
+    want(o, [cc, *FLAGS, "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", str(CSRC / "qinco_hip.hip"), "-o", str(o)])
     o = OBJ / "search_hip.o"
-    objs.append(o)
-    if force or not _newer(o, [CSRC / n for n in ("search_hip.hip", "knn_kernel.hpp", "abi_util.hpp", "mlp_args.hpp")]
-                           + [PKG.parent / "include" / "qinco_hip.h"]):
-        tasks.append((o, [cc, *FLAGS, "-c", str(CSRC / "search_hip.hip"), "-o", str(o)]))
+    want(o, [cc, *FLAGS, "-c", str(CSRC / "search_hip.hip"), "-o", str(o)])
     if tasks:
         if verbose:
             print(f"[qinco_amd.build] compiling {len(tasks)} object(s) for {ARCH}", file=sys.stderr)
         with cf.ThreadPoolExecutor(max_workers=jobs or min(len(tasks), os.cpu_count() or 4)) as ex:
-            for f in [ex.submit(_run, cmd) for _, cmd in tasks]:
+            for f in [ex.submit(_compile, o, cmd) for o, cmd in tasks]:
                 f.result()
-    for stale in OBJ.glob("*.o"):
+    for stale in OBJ.glob("mlp_*.o"):
         if stale not in objs:
-            stale.unlink()
-    if force or tasks or not _newer(LIB, objs):
-        _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)])
+            for suf in (".o", ".d", ".cmd"):
+                stale.with_suffix(suf).unlink(missing_ok=True)
+    if force or tasks or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
+        _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs), "-ldl"])
         if verbose:
             print(f"[qinco_amd.build] linked {LIB}", file=sys.stderr)
     return LIB

@@ -24,14 +24,8 @@
 namespace qinco {
 
 #define QINCO_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-// Bisection switches for the co-residency failure of this kernel (experiment builds only, scripts/build_exp_lib.py):
-//   1 ring registers pinned to VGPRs (hipcc lets the LDS reads land in AGPRs)      2 full s_waitcnt 0 behind every barrier
-//   4 __syncthreads() instead of the raw s_barrier                                 8 no read-ahead: fragment T is read at take<T>
-//  16 epilogue without the x loads (distances of garbage)                         64 lgkmcnt(0) joins the counted vmcnt in front of every barrier
-// 128 lgkmcnt(0) once, behind the bias fragments' reads
-#ifndef QINCO_EXP16
-#define QINCO_EXP16 0
-#endif
+// (The bisection switches that isolated the co-residency failure of this kernel in round 2 -- profiles/r02_mlp16_bisect.log,
+// DESIGN.md 3.1b -- are gone from this header; the commit history has them.)
 
 template <int D, int DE, int DH, int P>
 __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
@@ -68,8 +62,7 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
   };
   auto wait_vm = [&]<int N>() QINCO_LAMBDA {
     asm volatile("" ::: "memory");
-    if constexpr (QINCO_EXP16 & 64) __builtin_amdgcn_s_waitcnt(0x0070 | (N & 15) | ((N >> 4) << 14));   // + lgkmcnt(0)
-    else __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
     asm volatile("" ::: "memory");
   };
   static_for<P / 4 - 1>([&]<int i>() QINCO_LAMBDA { dma.template operator()<4 * i>(); });
@@ -80,23 +73,11 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
   auto take = [&]<int T>() QINCO_LAMBDA -> f32x4 {
     if constexpr ((T & 3) == 0) {
       wait_vm.template operator()<P / 4 - 3>();
-      if constexpr (QINCO_EXP16 & 4) __syncthreads();
-      else __builtin_amdgcn_s_barrier();
-      if constexpr (QINCO_EXP16 & 2) {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0);
-        asm volatile("" ::: "memory");
-      }
+      __builtin_amdgcn_s_barrier();
       dma.template operator()<T + P - 4>();
-    }
-    if constexpr (QINCO_EXP16 & 8) {
-      f32x4 w = myring[(T % P) * 64 + lane];
-      if constexpr (QINCO_EXP16 & 1) asm volatile("" : "+v"(w));
-      return w;
     }
     ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
     asm volatile("" ::: "memory");   // the ring reads keep their program order (see fragmm)
-    if constexpr (QINCO_EXP16 & 1) asm volatile("" : "+v"(ring[(T + 2) % 3]));
     return ring[T % 3];
   };
   auto skip_pad = [&]<int FROM, int TO>() QINCO_LAMBDA {
@@ -111,14 +92,10 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
     // ~75 % busy with this kernel's 1 KiB per wave per 128 cycles) the refill from L2 can land before a queued read executes:
     // about one wave in a hundred computed with a refilled (wrong) fragment.  The pin makes the fragment a register value at
     // this point of the program; asm volatile does not cross the barrier's fences.  (round-2 bisection)
-#if QINCO_EXP16 & 512   // experiment: pin every fragment (the first form of the fix: -3.6 % on the production shape)
-    pin4_v(w);
-#else
-    // Lighter form, as in mlp_kernel: the ring reads keep their program order (memory fence in take), LDS returns a wave's reads
-    // in order, so pinning the LAST fragment in front of each barrier covers the earlier ones; a section whose live fragments do
-    // not end on such a fragment finishes with lgkmcnt(0) (section_done).
+    // The ring reads keep their program order (memory fence in take), LDS returns a wave's reads in order, so pinning the LAST
+    // fragment in front of each barrier covers the earlier ones; a section whose live fragments do not end on such a fragment
+    // finishes with lgkmcnt(0) (section_done).  (Pinning every fragment, the first form of the fix, cost 3.6 %.)
     if constexpr ((T & 3) == 3) pin4_v(w);
-#endif
     static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA16(w[e], b[e], acc); });
   };
   auto section_done = [&]() QINCO_LAMBDA {   // every LDS read of this wave has completed (once per section)
@@ -152,11 +129,6 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
     y[ob] = take.template operator()<ob>();
     pin4_v(y[ob]);   // (see fragmm: the bias fragments land straight in y and would stay in flight for a whole section)
   });
-  if constexpr (QINCO_EXP16 & 128) {   // the bias fragments have left LDS before this wave goes on to the barriers that recycle their slots
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
-    asm volatile("" ::: "memory");
-  }
   skip_pad.template operator()<NEB, SL.T_BIAS>();
   wp += SL.T_BIAS * 64;
 
@@ -220,7 +192,7 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
     o = o + load_blk(xhptr + ob * 16);
     if (valid) *reinterpret_cast<f32x4*>(outp + ob * 16) = o;
     if (xptr) {
-      const f32x4 xb = (QINCO_EXP16 & 16) ? zero4 : load_blk(xptr + ob * 16);
+      const f32x4 xb = load_blk(xptr + ob * 16);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         s2 = fmaf(o[i], o[i], s2);

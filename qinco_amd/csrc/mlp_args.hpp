@@ -2,6 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#if defined(QINCO_TIMELINE) && !defined(QINCO_EXPERIMENT)
+#error "QINCO_TIMELINE (per-wave cycle stamps) belongs to experiment builds: scripts/build_exp_lib.py adds -DQINCO_EXPERIMENT"
+#endif
+
 namespace qinco {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -14,7 +14,8 @@
 // wrong weight fragment.  Round 2 found the cause (mlp16_kernel.hpp, fragmm): hipcc moves the consuming MFMAs
 // and the lgkmcnt wait of a fragment's LDS read below the s_barrier that licenses the refill of its ring slot.  With the
 // fragments pinned where they are consumed the kernels are exact at 1-3 workgroups per CU and nothing is padded any more.
-// QINCO_RING_PAD_KIB=n (experiments) still pads every shared-ring launch.
+// Experiment builds (-DQINCO_EXPERIMENT): QINCO_RING_PAD_KIB=n still pads every shared-ring launch.
+#ifdef QINCO_EXPERIMENT
 static unsigned exclusive_lds() {
   static const int env = [] {
     const char* e = getenv("QINCO_RING_PAD_KIB");
@@ -23,6 +24,9 @@ static unsigned exclusive_lds() {
   return ((QVAR & 64) && env >= 0) ? (unsigned)env * 1024u : 0u;
 }
 #define kExclusiveLds exclusive_lds()
+#else
+#define kExclusiveLds 0u
+#endif
 
 extern "C" __attribute__((visibility("hidden")))
 hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::MlpArgs* a, hipStream_t stream) {

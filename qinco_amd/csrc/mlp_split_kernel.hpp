@@ -433,6 +433,9 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
         sx = fmaf(o[i], e.xb[i], sx);
         xn = fmaf(e.xb[i], e.xb[i], xn);
       }
+    } else {   // decode: no distance, but the overflow check below still needs to see a non-finite output
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s2 = fmaf(o[i], o[i], s2);
     }
   };
   if constexpr (SPLIT_OUT) {
@@ -503,6 +506,8 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
     // an fp32 value beyond the fp16 range (|z'| > 65504) became inf in the split and NaN in the products: say so instead of
     // letting the selection sort a NaN (qinco_check / the host entry points report it; the fp32 path has no such limit)
     if (a.err && !(s2 < 3.0e38f)) *a.err = 2;
+  } else if (a.err && !(s2 < 3.0e38f)) {   // decode: this lane's part of |out|^2 is inf / NaN
+    *a.err = 2;
   }
   stamp(4);
   // no LDS-DMA may be in flight when the wave ends (its LDS could be handed to the next workgroup)

@@ -74,6 +74,7 @@ struct qinco_handle_s {
   int device = 0;
   int A = 0, B = 1;  // active search widths
   const MlpInstance* inst = nullptr;
+  int L_alg = 0;   // the model's own L (d.L is 1 for an L = 0 model: it runs with one all-zero block); FLOP accounting only
   StreamDims sd{};
 
   float* mean = nullptr;
@@ -102,7 +103,9 @@ struct qinco_handle_s {
   f32x4* ivf_stream = nullptr;      // centroids packed as MFMA A-operand fragments
   unsigned long long* ivf_best = nullptr;  // (max_batch) merged (distance, id) keys
   // fp16-filter passes of the IVF assignment (ivf_f16_kernel.hpp)
-  bool table_valu = false;          // QINCO_TABLE_VALU=1 at create: VALU pre-selection table kernel (A/B)
+  bool table_valu = false;          // QINCO_CREATE_TABLE_VALU: VALU pre-selection table kernel (A/B)
+  bool table_coop = true;           // small launches: the cooperative table kernel (QINCO_CREATE_TABLE_NO_COOP clears it)
+  long table_coop_max = 16384;      // ... up to this many groups
   bool ivf_f16 = false;
   void* ivf_h16 = nullptr;           // centroids as fp16 MFMA fragments
   float* ivf_cnorm_half = nullptr;   // -|c|^2 / 2
@@ -160,9 +163,10 @@ static int n_codes(const qinco_handle_s* h, int m) {
   return h->A;
 }
 
-static double mlp_flops_per_row(const qinco_desc& d) {
+static double mlp_flops_per_row(const qinco_handle_s* h) {
   // R_mlp = [De != D] 4 D De + 2 (De + D) De + 4 L De Dh
-  double f = 2.0 * (d.De + d.D) * d.De + 4.0 * d.L * (double)d.De * d.Dh;
+  const qinco_desc& d = h->d;
+  double f = 2.0 * (d.De + d.D) * d.De + 4.0 * h->L_alg * (double)d.De * d.Dh;
   if (d.De != d.D) f += 4.0 * d.D * d.De;
   return f;
 }
@@ -578,16 +582,78 @@ extern "C" int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh) {
   return find_mlp_instance(D, De, Dh, -1, -1) != nullptr;
 }
 
+// Diagnostic knobs of a handle (qinco_options in the ABI).  Experiment builds (-DQINCO_EXPERIMENT, scripts/) also read them from
+// the environment so that an unmodified caller can be A/B-ed; the shipping library has no environment switches.
+struct CreateOpts {
+  int flags = 0;
+  int mlp_P = -1, mlp_var = -1;
+  long table_coop_max = -1;
+};
+static const int kCreateFlagMask = QINCO_CREATE_SPLIT_F16 | QINCO_CREATE_IVF_FP32 | QINCO_CREATE_TABLE_VALU | QINCO_CREATE_DECODE_FOLDED |
+                                   QINCO_CREATE_TABLE_NO_COOP;
+
+static void env_opts(CreateOpts& o) {
+#ifdef QINCO_EXPERIMENT
+  if (const char* e = getenv("QINCO_SPLIT_F16")) if (atoi(e) > 0) o.flags |= QINCO_CREATE_SPLIT_F16;
+  if (getenv("QINCO_IVF_FP32")) o.flags |= QINCO_CREATE_IVF_FP32;
+  if (getenv("QINCO_TABLE_VALU")) o.flags |= QINCO_CREATE_TABLE_VALU;
+  if (getenv("QINCO_DECODE_FOLDED")) o.flags |= QINCO_CREATE_DECODE_FOLDED;
+  if (getenv("QINCO_TABLE_NO_COOP")) o.flags |= QINCO_CREATE_TABLE_NO_COOP;
+  if (const char* e = getenv("QINCO_TABLE_COOP_MAX")) o.table_coop_max = atol(e);
+  if (const char* e = getenv("QINCO_MLP_VARIANT")) sscanf(e, "%d,%d", &o.mlp_P, &o.mlp_var);
+#else
+  (void)o;
+#endif
+}
+
+static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpts opt, qinco_handle* out);
+
 extern "C" int qinco_create(const qinco_desc* desc, const qinco_weights* w, qinco_handle* out) {
-  // QINCO_SPLIT_F16=1: experiments / A-B runs of an unmodified caller
-  const char* e = getenv("QINCO_SPLIT_F16");
-  return qinco_create_ex(desc, w, (e && atoi(e) > 0) ? QINCO_CREATE_SPLIT_F16 : 0, out);
+  CreateOpts o;
+  env_opts(o);
+  return create_impl(desc, w, o, out);
 }
 
 extern "C" int qinco_create_ex(const qinco_desc* desc, const qinco_weights* w, int32_t create_flags, qinco_handle* out) {
+  if (create_flags & ~kCreateFlagMask) return fail(QINCO_ERR_INVALID, "qinco_create_ex: unknown flag bits 0x%x", create_flags);
+  CreateOpts o;
+  env_opts(o);
+  o.flags |= create_flags;
+  return create_impl(desc, w, o, out);
+}
+
+extern "C" int qinco_create_opt(const qinco_desc* desc, const qinco_weights* w, const qinco_options* opt, qinco_handle* out) {
+  CreateOpts o;
+  env_opts(o);
+  if (opt) {
+    if (opt->struct_bytes != (int32_t)sizeof(qinco_options))
+      return fail(QINCO_ERR_INVALID, "qinco_create_opt: struct_bytes %d, this library's qinco_options has %d", opt->struct_bytes,
+                  (int)sizeof(qinco_options));
+    if (opt->create_flags & ~kCreateFlagMask) return fail(QINCO_ERR_INVALID, "qinco_create_opt: unknown flag bits 0x%x", opt->create_flags);
+    o.flags |= opt->create_flags;
+    if (opt->mlp_P >= 0 || opt->mlp_var >= 0) { o.mlp_P = opt->mlp_P; o.mlp_var = opt->mlp_var; }
+    if (opt->table_coop_max >= 0) o.table_coop_max = (long)opt->table_coop_max;
+  }
+  return create_impl(desc, w, o, out);
+}
+
+static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpts opt, qinco_handle* out) {
+  const int create_flags = opt.flags;
   if (!desc || !w || !out) return fail(QINCO_ERR_INVALID, "qinco_create: null argument");
-  if (create_flags & ~QINCO_CREATE_SPLIT_F16) return fail(QINCO_ERR_INVALID, "qinco_create_ex: unknown flag bits 0x%x", create_flags);
-  const qinco_desc& d = *desc;
+  // A model without FFN blocks (L = 0) runs as L = 1 with an all-zero block: z + W_down relu(W_up z) = z + 0 exactly, and every
+  // kernel form (FOLD2 and the split form peel block 0, the 16-row tile form) then serves it without an instance of its own.
+  qinco_desc dpad = *desc;
+  qinco_weights wpad = *w;
+  std::vector<float> zero_block;
+  std::vector<const float*> zero_ptrs;
+  if (desc->L == 0 && desc->M > 1 && desc->De > 0 && desc->Dh > 0) {
+    zero_block.assign((size_t)desc->De * desc->Dh, 0.f);
+    zero_ptrs.assign((size_t)desc->M, zero_block.data());
+    dpad.L = 1;
+    wpad.up = wpad.down = zero_ptrs.data();
+    w = &wpad;
+  }
+  const qinco_desc& d = dpad;
   if (d.D <= 0 || d.De <= 0 || d.Dh <= 0 || d.M <= 0 || d.K <= 0 || d.L < 0 || d.max_batch <= 0)
     return fail(QINCO_ERR_INVALID, "qinco_create: non-positive hyper-parameter");
   if (d.D % 32 || d.De % 32 || d.Dh % 32)
@@ -600,8 +666,7 @@ extern "C" int qinco_create_ex(const qinco_desc* desc, const qinco_weights* w, i
   if (d.ivf_K > 0 && d.D != 32 && d.D != 96 && d.D != 128 && d.D != 256 && d.D != 768)
     return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: no IVF kernel instance for D=%d", d.D);
   if (!(w->data_std > 0.f)) return fail(QINCO_ERR_INVALID, "qinco_create: data_std must be > 0 (qinco_base.py:526)");
-  int want_P = -1, want_var = -1;  // A/B hook: QINCO_MLP_VARIANT="P,VAR" selects a non-production instance
-  if (const char* ev = getenv("QINCO_MLP_VARIANT")) sscanf(ev, "%d,%d", &want_P, &want_var);
+  const int want_P = opt.mlp_P, want_var = opt.mlp_var;  // diagnostics: a non-production instance of the shape
   const MlpInstance* fn = find_mlp_instance(d.D, d.De, d.Dh, want_P, want_var);
   if ((create_flags & QINCO_CREATE_SPLIT_F16) && d.M > 1) {
     // the split-fp16 instance of the shape (VAR bit 512); it peels FFN block 0 like FOLD2, so the model needs L >= 1
@@ -611,9 +676,8 @@ extern "C" int qinco_create_ex(const qinco_desc* desc, const qinco_weights* w, i
         const MlpInstance* c = find_mlp_instance(d.D, d.De, d.Dh, pp, 512 | 124);
         if (c && c->P == pp && c->var == (512 | 124)) sp = c;
       }
-    if (!sp || d.L < 1)
-      return fail(QINCO_ERR_UNSUPPORTED, "qinco_create_ex: no split-fp16 kernel instance for (D=%d, De=%d, Dh=%d, L=%d)", d.D, d.De,
-                  d.Dh, d.L);
+    if (!sp)
+      return fail(QINCO_ERR_UNSUPPORTED, "qinco_create_ex: no split-fp16 kernel instance for (D=%d, De=%d, Dh=%d)", d.D, d.De, d.Dh);
     fn = sp;
   }
   if (!fn && d.M > 1)
@@ -629,26 +693,21 @@ extern "C" int qinco_create_ex(const qinco_desc* desc, const qinco_weights* w, i
 
   qinco_handle_s* h = new qinco_handle_s();
   h->d = d;
+  h->L_alg = desc->L;
   h->A = d.A;
   h->B = d.B;
   h->inst = fn;
   h->std_ = w->data_std;
-  h->table_valu = getenv("QINCO_TABLE_VALU") != nullptr;
+  h->table_valu = (create_flags & QINCO_CREATE_TABLE_VALU) != 0;
+  h->table_coop = !(create_flags & QINCO_CREATE_TABLE_NO_COOP);
+  if (opt.table_coop_max >= 0) h->table_coop_max = opt.table_coop_max;
   const int kRing = fn ? fn->P : 8;
-  if (fn && (fn->var & 32) && d.L == 0) {  // FOLD2 peels FFN block 0: a model without FFN blocks takes the plain FOLD kernel
-    fn = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~32);
-    if (!fn || (fn->var & 32))
-      return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: L = 0 needs a kernel instance without FOLD2 for (D=%d, De=%d, Dh=%d)", d.D,
-                  d.De, d.Dh);
-    h->inst = fn;
-  }
   h->fold = fn && (fn->var & 16);
   h->fold2 = fn && (fn->var & 32);
   h->split16 = fn && (fn->var & 512);
-  if (h->split16 && d.L < 1) return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: the split-fp16 kernel needs L >= 1");
   const bool tile16 = fn && (fn->var & 128);
   h->sd = stream_dims(d.D, d.De, d.Dh, kRing, h->fold, h->fold2, tile16 ? 16 : 32);
-  if (h->fold && !getenv("QINCO_DECODE_FOLDED")) {
+  if (h->fold && !(create_flags & QINCO_CREATE_DECODE_FOLDED)) {
     const MlpInstance* di = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~(16 | 32));
     if (di && !(di->var & (16 | 32 | 128)) && di->P == fn->P) {
       h->dec_inst = di;
@@ -697,7 +756,7 @@ extern "C" int qinco_create_ex(const qinco_desc* desc, const qinco_weights* w, i
     if (m == 0) {
       if (d.ivf_K > 0) {
         if ((rc = upload_fragments(h, w->codebook[0], d.ivf_K, d.D, &h->ivf_stream))) return bail(rc);
-        if (!getenv("QINCO_IVF_FP32") && (rc = build_ivf_f16(h, w->codebook[0]))) return bail(rc);
+        if (!(create_flags & QINCO_CREATE_IVF_FP32) && (rc = build_ivf_f16(h, w->codebook[0]))) return bail(rc);
       } else if (mfma_table_ok(d)) {
         if ((rc = upload_fragments(h, w->codebook[0], d.K, d.D, &h->cb_stream[0]))) return bail(rc);
       }
@@ -892,22 +951,20 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
   HIP_TRY((unfolded ? h->dec_inst : h->inst)->fn(&a, st));
   if (h->prof) {
     HIP_TRY(hipEventRecord(e1, st));
-    h->prof_flops += (double)a.R * mlp_flops_per_row(h->d);
+    h->prof_flops += (double)a.R * mlp_flops_per_row(h);
   }
   return 0;
 }
 
 template <int D>
-static void launch_table_inst(const float* x, const float* xhat, int F, const f32x4* cs, const float* cn, long G, int T,
-                              int* ids, hipStream_t st) {
-  static const bool coop = getenv("QINCO_TABLE_NO_COOP") == nullptr;
-  static const long coop_max = [] { const char* e = getenv("QINCO_TABLE_COOP_MAX"); return e ? atol(e) : 16384L; }();
-  if (G <= coop_max && coop) {   // small launches: the four waves of a workgroup share 32 groups (ivf_kernel.hpp)
+static void launch_table_inst(const qinco_handle_s* h, const float* x, const float* xhat, int F, const f32x4* cs, const float* cn, long G,
+                              int T, int* ids, hipStream_t st) {
+  if (G <= h->table_coop_max && h->table_coop) {   // small launches: the four waves of a workgroup share 32 groups (ivf_kernel.hpp)
     hipLaunchKernelGGL((dist_topk_mfma_coop_kernel<D, 8>), dim3((unsigned)((G + 31) / 32)), dim3(256), 0, st, x, xhat, F, cs, cn, G, T,
                        ids);
     return;
   }
-  const int gpw = G <= 16384 ? 8 : 32;  // (QINCO_TABLE_NO_COOP: small launches with 8 groups per wave, the round-2 form)
+  const int gpw = G <= 16384 ? 8 : 32;  // (without the cooperative kernel: small launches with 8 groups per wave, the round-2 form)
   hipLaunchKernelGGL((dist_topk_mfma_kernel<D, 8>), dim3((unsigned)((G + 4 * gpw - 1) / (4 * gpw))), dim3(256), 0, st, x, xhat,
                      F, cs, cn, G, T, ids, gpw);
 }
@@ -917,11 +974,11 @@ static int launch_dist_topk(qinco_handle_s* h, const float* x, const float* xhat
   const qinco_desc& d = h->d;
   if (cstream && !h->table_valu) {
     switch (d.D) {
-      case 32: launch_table_inst<32>(x, xhat, F, cstream, cn, G, T, ids, st); break;
-      case 96: launch_table_inst<96>(x, xhat, F, cstream, cn, G, T, ids, st); break;
-      case 128: launch_table_inst<128>(x, xhat, F, cstream, cn, G, T, ids, st); break;
-      case 256: launch_table_inst<256>(x, xhat, F, cstream, cn, G, T, ids, st); break;
-      default: launch_table_inst<768>(x, xhat, F, cstream, cn, G, T, ids, st); break;
+      case 32: launch_table_inst<32>(h, x, xhat, F, cstream, cn, G, T, ids, st); break;
+      case 96: launch_table_inst<96>(h, x, xhat, F, cstream, cn, G, T, ids, st); break;
+      case 128: launch_table_inst<128>(h, x, xhat, F, cstream, cn, G, T, ids, st); break;
+      case 256: launch_table_inst<256>(h, x, xhat, F, cstream, cn, G, T, ids, st); break;
+      default: launch_table_inst<768>(h, x, xhat, F, cstream, cn, G, T, ids, st); break;
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1211,6 +1268,8 @@ extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int
   const int64_t pass = h->d.max_batch;
   const size_t crow = (size_t)h->d.M * code_size(code_dtype);
   const int64_t cap = n < pass ? n : pass;
+  // this call reports its own work only: a flag left behind by an unchecked device-pointer call is dropped
+  if (h->split16) HIP_TRY(hipMemset(h->err_flag, 0, sizeof(int)));
   if ((rc = ensure_stage(&h->stage_x, &h->stage_x_bytes, (size_t)cap * rowb))) return rc;
   if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, (size_t)cap * crow))) return rc;
   if (xhat_out && (rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, (size_t)cap * h->d.D * 4))) return rc;
@@ -1303,7 +1362,7 @@ extern "C" int qinco_profile_read(qinco_handle h, double* mlp_ms, int64_t* mlp_l
 extern "C" double qinco_flops_per_vector_encode(qinco_handle h) {
   if (!h) return 0.0;
   const qinco_desc& d = h->d;
-  const double rm = mlp_flops_per_row(d);
+  const double rm = mlp_flops_per_row(h);
   double total = 2.0 * d.D * (d.ivf_K > 0 ? d.ivf_K : d.K);  // step 0 table
   int F = (d.M == 1 || d.ivf_K > 0) ? 1 : (h->B < d.K ? h->B : d.K);
   for (int m = 1; m < d.M; ++m) {
@@ -1315,6 +1374,21 @@ extern "C" double qinco_flops_per_vector_encode(qinco_handle h) {
     F = Fout < F * Ae ? Fout : (int)(F * Ae);
   }
   return total;
+}
+
+extern "C" int qinco_describe(qinco_handle h, char* buf, int32_t cap) {
+  if (!h) return fail(QINCO_ERR_INVALID, "qinco_describe: null handle");
+  char tmp[512];
+  const MlpInstance* i = h->inst;
+  const int n = snprintf(tmp, sizeof(tmp), "mlp=%dx%dx%d P=%d var=%d decode_var=%d form=%s tile=%d table=%s ivf=%s", h->d.D, h->d.De, h->d.Dh,
+                         i ? i->P : 0, i ? i->var : -1, h->dec_inst ? h->dec_inst->var : -1, h->split16 ? "split-fp16" : "fp32",
+                         (i && (i->var & 128)) ? 16 : 32, (mfma_table_ok(h->d) && !h->table_valu) ? "mfma" : "valu",
+                         h->d.ivf_K == 0 ? "none" : (h->ivf_f16 ? "fp16-filter+fp32" : "fp32"));
+  if (buf && cap > 0) {
+    strncpy(buf, tmp, (size_t)cap - 1);
+    buf[cap - 1] = 0;
+  }
+  return n + 1;
 }
 
 extern "C" int qinco_ivf_last_stats(qinco_handle h, int64_t* candidates, int32_t* fell_back) {
@@ -1333,7 +1407,7 @@ extern "C" int qinco_ivf_last_stats(qinco_handle h, int64_t* candidates, int32_t
 
 extern "C" double qinco_flops_per_vector_decode(qinco_handle h) {
   if (!h) return 0.0;
-  return (double)(h->d.M - 1) * mlp_flops_per_row(h->d);
+  return (double)(h->d.M - 1) * mlp_flops_per_row(h);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -25,12 +25,25 @@ class QincoEngine:
     """
 
     def __init__(self, cfg: QincoConfig, state_dict: dict, max_batch: int = 8192, device: Optional[int] = None,
-                 split_f16: bool = False):
+                 split_f16: bool = False, diagnostics: Optional[dict] = None):
         """split_f16: opt-in split-fp16 evaluation of the FFN blocks (include/qinco_hip.h, QINCO_CREATE_SPLIT_F16): several
-        times the fp32-MFMA throughput, fp32-class accuracy but not the fp32 path's bits."""
+        times the fp32-MFMA throughput, fp32-class accuracy but not the fp32 path's bits.
+        diagnostics: qinco_options knobs for A/B runs and the race-detector tests -- ivf_fp32, table_valu, decode_folded,
+        table_no_coop (bools), mlp_variant=(P, VAR) (a non-production kernel instance of csrc/shapes.def), table_coop_max."""
         self.lib = _lib.load()
         self.cfg = cfg
         self.split_f16 = bool(split_f16)
+        diag = dict(diagnostics or {})
+        flags = _lib.CREATE_SPLIT_F16 if self.split_f16 else 0
+        for key, bit in (("ivf_fp32", _lib.CREATE_IVF_FP32), ("table_valu", _lib.CREATE_TABLE_VALU),
+                         ("decode_folded", _lib.CREATE_DECODE_FOLDED), ("table_no_coop", _lib.CREATE_TABLE_NO_COOP)):
+            if diag.pop(key, False):
+                flags |= bit
+        P, var = diag.pop("mlp_variant", None) or (-1, -1)
+        opts = _lib.QincoOptions(struct_bytes=C.sizeof(_lib.QincoOptions), create_flags=flags, mlp_P=int(P), mlp_var=int(var),
+                                 table_coop_max=int(diag.pop("table_coop_max", -1)))
+        if diag:
+            raise ValueError(f"unknown diagnostics keys: {sorted(diag)}")
         self.max_batch = int(max_batch)
         self._h = C.c_void_p()
         if device is not None:
@@ -86,11 +99,15 @@ class QincoEngine:
         w.cat_w, w.cat_b, w.up, w.down = cw, cbias, up, down
         desc = _lib.QincoDesc(D=D, De=De, Dh=Dh, L=L, M=M, K=K, A=cfg.A, B=cfg.B,
                               qinco1_mode=int(cfg.qinco1_mode), ivf_K=int(cfg.ivf_K or 0), max_batch=self.max_batch)
-        if self.split_f16:
-            _lib.check(self.lib.qinco_create_ex(C.byref(desc), C.byref(w), _lib.CREATE_SPLIT_F16, C.byref(self._h)))
-        else:
-            _lib.check(self.lib.qinco_create(C.byref(desc), C.byref(w), C.byref(self._h)))
+        _lib.check(self.lib.qinco_create_opt(C.byref(desc), C.byref(w), C.byref(opts), C.byref(self._h)))
         self._keep = []  # weights now live on the device
+        self.device = None
+        try:   # the HIP device the handle is bound to (= the current one at create), for stream look-ups on multi-GPU processes
+            import sys
+            if "torch" in sys.modules:
+                self.device = sys.modules["torch"].cuda.current_device()
+        except Exception:
+            pass
         self.data_mean = sd["data_mean"]
         self.data_std = F32(std)
         self.A, self.B = cfg.A, cfg.B
@@ -114,10 +131,12 @@ class QincoEngine:
         self.A, self.B = A, B
 
     # ------------------------------------------------------------------------------------------
-    def encode(self, x, code_dtype=np.int64, return_xhat: bool = False, normalised: bool = False):
+    def encode(self, x, code_dtype=np.int64, return_xhat: bool = False, normalised: bool = False, check: Optional[bool] = None):
         """x: (n, D) float32 / uint8, numpy (host path) or torch CUDA tensor (device path, async on the current
         stream).  Returns codes (n, M) [and the normalised reconstruction (n, D)].  normalised=True: x is already
-        (x - mean) / std, i.e. QINCoInferenceWrapper.encode instead of forward."""
+        (x - mean) / std, i.e. QINCoInferenceWrapper.encode instead of forward.
+        check (device path): wait for the stream and raise if the split-fp16 form left the fp16 range (qinco_check); default:
+        only when the engine was created with split_f16 -- the fp32 path cannot fail on the device and stays asynchronous."""
         M, D = self.cfg.M_total, self.cfg.D
         flags = _lib.FLAG_NORMALISED if normalised else 0
         if _is_torch(x) and x.is_cuda:
@@ -137,6 +156,8 @@ class QincoEngine:
                 self._h, x.data_ptr(), _lib.X_F32 if x.dtype == torch.float32 else _lib.X_U8,
                 x.stride(0) * x.element_size(), n, codes.data_ptr(), _CODE_DT[np.dtype(code_dtype)],
                 xhat.data_ptr() if xhat is not None else None, flags, st))
+            if self.split_f16 if check is None else check:
+                _lib.check(self.lib.qinco_check(self._h, st))
             return (codes, xhat) if return_xhat else codes
         if _is_torch(x):
             x = x.detach().cpu().numpy()
@@ -193,12 +214,14 @@ class QincoEngine:
         return out
 
     def check_codes(self, stream=None):
-        """Wait for `stream` (default: the current torch stream, else the null stream) and raise IndexError if a
-        device-path decode since the last check saw a code outside [0, K) (include/qinco_hip.h: qinco_check)."""
+        """Wait for `stream` (default: the current torch stream OF THE ENGINE'S DEVICE, else the null stream) and raise
+        IndexError if a device-path call since the last check saw a code outside [0, K) or a split-fp16 overflow
+        (include/qinco_hip.h: qinco_check)."""
         if stream is None:
             import sys
             torch = sys.modules.get("torch")
-            stream = torch.cuda.current_stream().cuda_stream if torch is not None and torch.cuda.is_available() else None
+            stream = (torch.cuda.current_stream(self.device).cuda_stream
+                      if torch is not None and torch.cuda.is_available() else None)
         _lib.check(self.lib.qinco_check(self._h, stream))
 
     # ------------------------------------------------------------------------------------------
@@ -215,6 +238,14 @@ class QincoEngine:
         c, f = C.c_int64(), C.c_int32()
         _lib.check(self.lib.qinco_ivf_last_stats(self._h, C.byref(c), C.byref(f)))
         return {"candidates": c.value, "fell_back": bool(f.value)}
+
+    def describe(self) -> str:
+        """qinco_describe: which kernel instances / arithmetic form serve this handle."""
+        buf = C.create_string_buffer(512)
+        n = self.lib.qinco_describe(self._h, buf, 512)
+        if n < 0:
+            _lib.check(n)
+        return buf.value.decode()
 
     def flops_per_vector(self, what: str = "encode") -> float:
         fn = self.lib.qinco_flops_per_vector_encode if what == "encode" else self.lib.qinco_flops_per_vector_decode

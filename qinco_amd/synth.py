@@ -66,3 +66,36 @@ def synth_codes(cfg: QincoConfig, n: int, seed: int = 7) -> np.ndarray:
     """Uniform random codes (M, n) int64 for decode tests / the structured S1 inputs."""
     rs = np.random.RandomState(seed)
     return np.stack([rs.randint(0, k, size=n) for k in cfg.K_vals]).astype(np.int64)
+
+
+# Normalisation regimes of the reference's datasets (magnitudes of qinco/qinco_tasks.py:516-527: BigANN bytes with per-dimension
+# means of 11-93 and a global std of 36.59; FB-ssnpp bytes around 128 with std 22.1; Contriever floats with std 0.0583; Deep1B
+# floats with std 0.102).  Synthetic values of those magnitudes -- the tables themselves are not reproduced.
+REGIMES = {
+    "bigann": dict(dtype="u8", std=36.5888),
+    "ssnpp": dict(dtype="u8", std=22.1006),
+    "contriever": dict(dtype="f32", std=0.0583),
+    "deep": dict(dtype="f32", std=0.1020),
+}
+
+
+def apply_regime(cfg: QincoConfig, sd: dict, regime: str, seed: int = 0) -> dict:
+    """Replace data_mean / data_std of a synthetic checkpoint by constants of a real dataset's magnitude."""
+    rs = np.random.RandomState(seed + 7001)
+    D = cfg.D
+    mean = {"bigann": lambda: 12.0 + 55.0 * rs.rand(D) ** 2,
+            "ssnpp": lambda: 128.0 + 0.04 * rs.randn(D),
+            "contriever": lambda: -0.015 + 0.01 * rs.randn(D),
+            "deep": lambda: 0.03 * rs.randn(D)}[regime]()
+    out = dict(sd)
+    out["data_mean"] = mean.astype(F32)
+    out["data_std"] = np.asarray(REGIMES[regime]["std"], dtype=F32)
+    return out
+
+
+def regime_vectors(cfg: QincoConfig, sd: dict, n: int, regime: str, seed: int = 42) -> np.ndarray:
+    """Inputs in the dataset's own storage type: uint8 rows (clipped to [0, 255], like SIFT bytes) or float32 rows."""
+    x = synth_vectors(cfg, sd, n, seed)
+    if REGIMES[regime]["dtype"] == "u8":
+        return np.clip(np.rint(x), 0, 255).astype(np.uint8)
+    return x

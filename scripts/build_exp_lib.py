@@ -10,7 +10,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from qinco_amd import build as B  # noqa: E402
 
-name, defs = sys.argv[1], sys.argv[2].split()
+name, defs = sys.argv[1], ["-DQINCO_EXPERIMENT"] + sys.argv[2].split()
 shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[3:]]
 B.build()
 out_dir = ROOT / "scripts" / "exp_libs"

@@ -29,8 +29,11 @@ sys.path.insert(0, "/root/reference")
 from qinco.model import QINCo, QINCoInferenceWrapper  # noqa: E402  (the reference)
 from qinco.model.qinco_base import IVFBook  # noqa: E402
 
-from qinco_amd.config import QincoConfig, preset  # noqa: E402
-from qinco_amd.synth import synth_codes, synth_state_dict, synth_vectors  # noqa: E402
+sys.path.insert(0, str(HERE))
+from cases import CASES, case_model  # noqa: E402  (the case table, shared with tests/conftest.py)
+from make_trained import clustered_rows  # noqa: E402
+from qinco_amd.config import QincoConfig  # noqa: E402
+from qinco_amd.synth import regime_vectors, synth_codes, synth_vectors  # noqa: E402
 from oracle.qinco_oracle import OracleQINCo  # noqa: E402
 
 torch.set_num_threads(8)
@@ -69,45 +72,32 @@ def build_reference(cfg: QincoConfig, sd: dict):
     return model, wrapper
 
 
-# name -> (config, seed, n_encode, structured?)
-CASES = {
-    "tiny_proj_beam": (QincoConfig(D=32, M=4, K=256, L=2, de=64, dh=96, A=8, B=4), 11, 256),
-    "tiny_proj_greedyA": (QincoConfig(D=32, M=4, K=256, L=2, de=64, dh=96, A=8, B=1), 12, 256),
-    "tiny_id_qinco1": (QincoConfig(D=32, M=4, K=256, L=2, de=None, dh=64, A=0, B=1, qinco1_mode=True), 13, 256),
-    "tiny_id_A0_beam": (QincoConfig(D=32, M=3, K=256, L=1, de=None, dh=64, A=0, B=3, qinco1_mode=False), 14, 64),
-    "tiny_proj_dh128": (QincoConfig(D=32, M=4, K=256, L=3, de=64, dh=128, A=8, B=4), 18, 256),   # even block counts: the split-fp16 form
-    "C1_qinco1_8x8": (preset("qinco1", D=128, M=8), 1235, 128),
-    "C2_qinco2L_8x8_b8": (preset("qinco2-L", D=128, M=8, B=8), 1236, 64),
-    "C2_qinco2L_8x8_b1": (preset("qinco2-L", D=128, M=8, B=1), 1236, 64),
-    "C4_qinco2L_d768_b8": (preset("qinco2-L", D=768, M=8, B=8), 1238, 32),     # BASELINE configs[3] at its real depth
-    "C3_qinco2L_16x8_b8": (preset("qinco2-L", D=128, M=16, B=8), 1237, 64),    # BASELINE configs[2]: M = 16 steps
-    "C2_qinco2L_8x8_b32": (preset("qinco2-L", D=128, M=8, B=32), 1236, 32),    # the presets' own search width (qinco2-L.yaml:13)
-    "tiny_smallK_wideB": (QincoConfig(D=32, M=4, K=64, L=2, de=64, dh=96, A=8, B=128), 17, 64),   # B > K: beam grows past beam_0
-    "qinco1_d768": (preset("qinco1", D=768, M=3), 1241, 32),   # De = D = 768: the 16-row tile kernel's shape
-    # IVF-QINCo: coarse step of ivf_K centroids, beam_0 = 1, first QINCo step takes max(A, B)
-    "tiny_ivf_beam": (QincoConfig(D=32, M=3, K=256, L=2, de=64, dh=96, A=4, B=8, ivf_K=2048), 15, 256),
-    "tiny_ivf_greedy_id": (QincoConfig(D=32, M=3, K=256, L=2, de=None, dh=64, A=8, B=1, ivf_K=1024), 16, 256),
-    "ivf_qinco2S_d128": (preset("qinco2-S", D=128, M=4, B=8, ivf_K=65536), 1240, 64),
-}
-
-
-def run_case(name: str, cfg: QincoConfig, seed: int, n: int) -> dict:
-    sd = synth_state_dict(cfg, seed)
+def run_case(name: str) -> dict:
+    c = CASES[name]
+    cfg, sd = case_model(name)
+    seed, n = c.seed, c.n
     model, wrapper = build_reference(cfg, sd)
     oracle = OracleQINCo.from_config(cfg, sd)
 
-    x0 = synth_vectors(cfg, sd, n, seed=seed + 1)
+    if c.ckpt:          # held-out rows of the mixture the checkpoint was trained on
+        x0 = clustered_rows(c.data, n, cfg.D, seed, part=1)
+    elif c.regime:      # the dataset's own storage type (uint8 / float32) at its normalisation magnitude
+        x0 = regime_vectors(cfg, sd, n, c.regime, seed=seed + 1)
+    else:
+        x0 = synth_vectors(cfg, sd, n, seed=seed + 1)
     # S1 "structured" half: x = decode(random codes) + small noise, so that beams really compete
     rc = synth_codes(cfg, n // 2, seed=seed + 2)
     with torch.no_grad():
         xs = model(torch.from_numpy(rc), step="decode").numpy()
-    xs = (xs + 0.05 * float(sd["data_std"]) * np.random.RandomState(seed + 3).randn(*xs.shape)).astype(np.float32)
-    x = np.concatenate([x0[: n - n // 2], xs]).astype(np.float32)
+    xs = xs + 0.05 * float(sd["data_std"]) * np.random.RandomState(seed + 3).randn(*xs.shape)
+    if x0.dtype == np.uint8:
+        xs = np.clip(np.rint(xs), 0, 255)
+    x = np.concatenate([x0[: n - n // 2], xs.astype(x0.dtype)])
 
     out = {"x": x}
     wrapper_ok = wrapper is not None
     with torch.no_grad():
-        xt = torch.from_numpy(x)
+        xt = torch.from_numpy(x).to(torch.float32)      # uint8 rows: search_tasks.py:109-110
         try:
             codes_base = model(xt, step="encode").numpy()  # (M, N)
         except RuntimeError as e:   # the base model's step 0 asks topk for B > K entries; the inference wrapper clamps beam_0
@@ -133,7 +123,7 @@ def run_case(name: str, cfg: QincoConfig, seed: int, n: int) -> dict:
 
     # oracle trace: pre-selection ids and selection margins (near-tie diagnostics)
     trace: dict = {}
-    xn = (x - oracle.data_mean) / oracle.data_std
+    xn = (x.astype(np.float32) - oracle.data_mean) / oracle.data_std
     codes_o, xhat_o = oracle.encode(xn, trace)
     codes_ref = out["codes_wrapper"] if "codes_wrapper" in out else out["codes_base"]
     agree = float((codes_o.T == codes_ref).all(axis=1).mean())
@@ -155,7 +145,7 @@ def run_case(name: str, cfg: QincoConfig, seed: int, n: int) -> dict:
         d0 = np.sort(trace["d0"], axis=-1)
         out["ivf_rel_margin"] = ((d0[:, 1] - d0[:, 0]) / np.maximum(np.abs(d0[:, 1]), 1e-12)).astype(np.float32)
     out["select_rel_margin"] = np.stack(margins, axis=1).astype(np.float32)  # (N, M_total-1)
-    mse_ref = float(((x - dec) ** 2).sum(-1).mean())
+    mse_ref = float(((x.astype(np.float32) - dec) ** 2).sum(-1).mean())
     out["mse"] = np.float64(mse_ref)
     print(f"{name:24s} N={len(x):4d} wrapper==base: "
           f"{bool((out.get('codes_base', codes_ref) == codes_ref).all())}  oracle==ref rows: {agree:.4f}  "
@@ -166,8 +156,7 @@ def run_case(name: str, cfg: QincoConfig, seed: int, n: int) -> dict:
 def write_tiny_checkpoint():
     """A checkpoint written by the reference's own save_model (qinco/utils.py:100-137)."""
     from qinco.utils import SharedCfgState, save_model
-    cfg, seed, _ = CASES["tiny_proj_beam"]
-    sd = synth_state_dict(cfg, seed)
+    cfg, sd = case_model("tiny_proj_beam")
     model, _ = build_reference(cfg, sd)
     path = HERE / "tiny_ckpt.pt"
     c = SharedCfgState(dict(output=str(path), K=cfg.K, M=cfg.M, de=cfg.de, dh=cfg.dh, L=cfg.L, A=cfg.A, B=cfg.B,
@@ -184,8 +173,7 @@ def run_search_case() -> dict:
     approx_pairwise_distance (qinco/utils.py:336-346): encode + decode the database with the reference wrapper,
     distances of query batches of 100 to the reconstructions, argsort, first 100 columns, recall of gt[:, 0]."""
     from qinco.utils import approx_pairwise_distance
-    cfg, seed, _ = CASES["tiny_proj_beam"]
-    sd = synth_state_dict(cfg, seed)
+    cfg, sd = case_model("tiny_proj_beam")
     model, wrapper = build_reference(cfg, sd)
     N, Q, nshort = 3000, 150, 100
     # clustered database so that near neighbours exist: vectors = decode(random codes) + noise; queries = db rows + noise
@@ -223,10 +211,10 @@ if __name__ == "__main__":
     only = sys.argv[1:]
     if not only or "search_small_db" in only:
         np.savez_compressed(HERE / "search_small_db.npz", **run_search_case())
-    for name, (cfg, seed, n) in CASES.items():
+    for name in CASES:
         if only and name not in only:
             continue
-        out = run_case(name, cfg, seed, n)
+        out = run_case(name)
         np.savez_compressed(HERE / f"{name}.npz", **out)
     if not only:
         write_tiny_checkpoint()

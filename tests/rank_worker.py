@@ -20,7 +20,7 @@ def main():
     dev_input = len(sys.argv) > 7
     import torch
     import torch.distributed as dist
-    from conftest import golden_cases
+    from conftest import golden_model
     from qinco_amd import synth_state_dict, synth_vectors
     from qinco_amd.encode_db import encode_database
     from qinco_amd.model import QINCoHIP
@@ -33,8 +33,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg, seed = golden_cases()["tiny_proj_beam"]
-    sd = synth_state_dict(cfg, seed)
+    cfg, sd = golden_model("tiny_proj_beam")
     model = QINCoHIP(cfg, sd, max_batch=256)
     db = synth_vectors(cfg, sd, n, seed=4)
     to_device = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if dev_input else None

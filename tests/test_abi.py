@@ -77,13 +77,22 @@ def test_create_ex_validates_its_flags_before_touching_the_device(lib):
     d = _lib.QincoDesc(D=128, De=384, Dh=384, L=16, M=2, K=256, A=16, B=8, qinco1_mode=0, ivf_K=0, max_batch=64)
     w = _lib.QincoWeights()
     w.data_std = 1.0
-    assert lib.qinco_create_ex(C.byref(d), C.byref(w), 2, C.byref(h)) == -1
+    assert lib.qinco_create_ex(C.byref(d), C.byref(w), 1 << 10, C.byref(h)) == -1
     assert b"unknown flag" in lib.qinco_last_error()
     d.Dh = 96                                   # (128, 384, 96) has no instance at all, let alone a split one
     assert lib.qinco_create_ex(C.byref(d), C.byref(w), _lib.CREATE_SPLIT_F16, C.byref(h)) == -3
-    d.Dh, d.L = 384, 0                          # the split form peels FFN block 0: L = 0 is refused
-    assert lib.qinco_create_ex(C.byref(d), C.byref(w), _lib.CREATE_SPLIT_F16, C.byref(h)) == -3
     assert b"split-fp16" in lib.qinco_last_error()
+    d.Dh, d.L = 384, 0                          # L = 0 runs as one all-zero FFN block: accepted, the next check (weights) fires
+    assert lib.qinco_create_ex(C.byref(d), C.byref(w), _lib.CREATE_SPLIT_F16, C.byref(h)) == -1
+    assert b"missing data_mean" in lib.qinco_last_error()
+    # qinco_create_opt: the options struct carries its own size; a mismatch (an older / newer header) is an argument error
+    o = _lib.QincoOptions(struct_bytes=C.sizeof(_lib.QincoOptions) - 8, create_flags=0, mlp_P=-1, mlp_var=-1, table_coop_max=-1)
+    assert lib.qinco_create_opt(C.byref(d), C.byref(w), C.byref(o), C.byref(h)) == -1
+    assert b"struct_bytes" in lib.qinco_last_error()
+    o.struct_bytes = C.sizeof(_lib.QincoOptions)
+    o.create_flags = 1 << 10
+    assert lib.qinco_create_opt(C.byref(d), C.byref(w), C.byref(o), C.byref(h)) == -1
+    assert b"unknown flag" in lib.qinco_last_error()
     cfg = QincoConfig(D=32, M=2, K=256, L=1, de=64, dh=96)          # odd number of hidden blocks: no split instance
     with pytest.raises(NotImplementedError, match="split-fp16"):
         QincoEngine(cfg, synth_state_dict(cfg, 1), split_f16=True)

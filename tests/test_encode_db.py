@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, golden_cases, make_oracle
+from conftest import ROOT, golden_model, make_oracle
 
 
 def test_shard_bounds_match_reference_formula():
@@ -52,9 +52,7 @@ class OracleModel:
     """Stand-in with the reference model's call signature (tests only)."""
 
     def __init__(self, name):
-        from qinco_amd import synth_state_dict
-        self.cfg, seed = golden_cases()[name]
-        self.sd = synth_state_dict(self.cfg, seed)
+        self.cfg, self.sd = golden_model(name)
         self.o = make_oracle(self.cfg, self.sd)
 
     def __call__(self, x, step):

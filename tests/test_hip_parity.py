@@ -8,7 +8,7 @@ row must have a recorded relative margin below NEAR_TIE, and the test prints the
 import numpy as np
 import pytest
 
-from conftest import ROOT, assert_only_near_ties, golden_cases, load_golden, make_oracle, ref_codes
+from conftest import ROOT, assert_only_near_ties, golden_model, golden_names, load_golden, make_oracle, ref_codes
 
 pytestmark = pytest.mark.gpu
 
@@ -23,8 +23,7 @@ def engines():
 
     def get(name):
         if name not in cache:
-            cfg, seed = golden_cases()[name]
-            sd = synth_state_dict(cfg, seed)
+            cfg, sd = golden_model(name)
             cache[name] = (cfg, sd, QincoEngine(cfg, sd, max_batch=1024))
         return cache[name]
     yield get
@@ -37,7 +36,9 @@ def rel_err(a, b):
 
 
 def check_encode_against_golden(eng, name, g):
-    codes, xhat = eng.encode(g["x"], return_xhat=True)
+    x = g["x"]                                            # float32, or uint8 rows for the byte datasets' regimes
+    xf = x.astype(np.float32)
+    codes, xhat = eng.encode(x, return_xhat=True)
     want = ref_codes(g)
     assert codes.shape == want.shape and codes.dtype == np.int64
     bad = np.nonzero((codes != want).any(axis=1))[0]
@@ -51,24 +52,28 @@ def check_encode_against_golden(eng, name, g):
         assert first > 0 or "ivf_rel_margin" in g, "step-0 codes can only differ on an exact tie"
         assert m < NEAR_TIE, f"row {i}: codes differ although the reference margin is {m:.3e}"
     # (no cap on the count: every differing row has just been shown to sit on a rounding-level tie of the reference)
+    if len(bad):   # ... and must be a row the reference algorithm itself produces when those ties fall the other way
+        oracle = make_oracle(*golden_model(name))
+        replay, _ = oracle.encode((xf[bad] - oracle.data_mean) / oracle.data_std, prefer=codes[bad], tie=NEAR_TIE)
+        assert np.array_equal(replay.T, codes[bad]), f"{name}: tie-side rows not reachable by the oracle"
     ok = np.setdiff1d(np.arange(len(want)), bad)
     if "xhat_norm_wrapper" in g:
         assert rel_err(xhat[ok], g["xhat_norm_wrapper"][ok]) < REL_TOL
     # the full pipeline (encode -> decode) vs the reference's: row by row where the codes agree, so the MSE over those
-    # rows is within REL_TOL; a row that took the other side of a tie must still be as good a reconstruction
+    # rows is within REL_TOL
     dec = eng.decode(codes)
     assert rel_err(dec[ok], g["decoded"][ok]) < REL_TOL
-    err_g = ((g["x"] - dec) ** 2).sum(-1)
-    err_r = ((g["x"] - g["decoded"]) ** 2).sum(-1)
+    err_g = ((xf - dec) ** 2).sum(-1)
+    err_r = ((xf - g["decoded"]) ** 2).sum(-1)
     assert abs(err_g[ok].mean() - err_r[ok].mean()) / err_r[ok].mean() < REL_TOL
     if len(bad) == 0:
         assert abs(float(err_g.mean()) - float(g["mse"])) / float(g["mse"]) < REL_TOL
-    else:
-        assert abs(err_g[bad].mean() - err_r[bad].mean()) / err_r[bad].mean() < 2e-2
+    else:          # tie-side rows: decode of the engine's codes against the oracle's decode of the same codes
+        assert rel_err(dec[bad], oracle(codes[bad].T, step="decode")) < REL_TOL
     return len(bad)
 
 
-@pytest.mark.parametrize("name", list(golden_cases().keys()))
+@pytest.mark.parametrize("name", golden_names())
 def test_encode_matches_reference_golden(engines, name):
     cfg, sd, eng = engines(name)
     check_encode_against_golden(eng, name, load_golden(name))
@@ -76,7 +81,10 @@ def test_encode_matches_reference_golden(engines, name):
 
 # ---- the opt-in split-fp16 form of the FFN blocks (QINCO_CREATE_SPLIT_F16, csrc/mlp_split_kernel.hpp): same bars ----------
 SPLIT_CASES = ["tiny_proj_dh128", "C2_qinco2L_8x8_b8", "C2_qinco2L_8x8_b1", "C3_qinco2L_16x8_b8", "C2_qinco2L_8x8_b32",
-               "C4_qinco2L_d768_b8", "C1_qinco1_8x8", "ivf_qinco2S_d128"]
+               "C4_qinco2L_d768_b8", "C1_qinco1_8x8", "ivf_qinco2S_d128",
+               # round 3: checkpoints trained by the reference, and the datasets' real normalisation magnitudes / byte inputs
+               # (the split form picks its power-of-two operand scalings from the weights: this is where that could break)
+               "trained_qinco2S", "trained_qinco2S_b1", "trained_qinco1", "norm_bigann_u8", "norm_ssnpp_u8", "norm_contriever"]
 
 
 @pytest.fixture(scope="module")
@@ -86,8 +94,7 @@ def split_engines():
 
     def get(name):
         if name not in cache:
-            cfg, seed = golden_cases()[name]
-            sd = synth_state_dict(cfg, seed)
+            cfg, sd = golden_model(name)
             cache[name] = (cfg, sd, QincoEngine(cfg, sd, max_batch=1024, split_f16=True))
         return cache[name]
     yield get
@@ -165,9 +172,14 @@ def test_split_f16_instances_of_the_other_dataset_dimensions(model, D):
         eng = QincoEngine(cfg, sd, max_batch=2048, split_f16=split)
         out[split] = (eng.encode(x), eng.decode(codes))
         eng.close()
-    differ = int((out[True][0] != out[False][0]).any(axis=1).sum())
-    print(f"{model} D={D}: {differ} of 2048 rows differ between the split and the fp32 path")
-    assert differ <= 2048 // 100
+    bad = np.nonzero((out[True][0] != out[False][0]).any(axis=1))[0]
+    print(f"{model} D={D}: {len(bad)} of 2048 rows differ between the split and the fp32 path")
+    assert len(bad) <= 2048 // 100
+    if len(bad):   # the margin rule, for both forms, against the oracle (not merely against each other)
+        oracle = make_oracle(cfg, sd)
+        want = oracle(x[bad], step="encode").T
+        for split in (False, True):
+            assert_only_near_ties(oracle, x[bad], out[split][0][bad], want, NEAR_TIE, f"{model} D={D} split={split}")
     assert rel_err(out[True][1], out[False][1]) < REL_TOL
 
 
@@ -202,7 +214,7 @@ def test_split_f16_against_the_fp32_path_at_the_bench_shape():
         QincoEngine(tiny, synth_state_dict(tiny, 3), max_batch=64, split_f16=True)
 
 
-@pytest.mark.parametrize("name", list(golden_cases().keys()))
+@pytest.mark.parametrize("name", golden_names())
 def test_decode_matches_reference_golden(engines, name):
     cfg, sd, eng = engines(name)
     g = load_golden(name)
@@ -258,6 +270,8 @@ def test_input_formats(engines):
     xu8 = rs.randint(0, 256, size=(300, cfg.D)).astype(np.uint8)
     base = eng.encode(xu8.astype(np.float32))
     assert np.array_equal(eng.encode(xu8), base)                     # uint8 rows (.to(float32), search_tasks.py:110)
+    oracle = make_oracle(cfg, sd)                                    # ... and against the oracle, not only against itself
+    assert_only_near_ties(oracle, xu8, base, oracle(xu8.astype(np.float32), step="encode").T, NEAR_TIE, "uint8 input")
     # bvecs-style rows: 4-byte header + D bytes, strided view (datasets.py:102-120)
     raw = np.zeros((300, cfg.D + 4), np.uint8)
     raw[:, 4:] = xu8
@@ -422,26 +436,32 @@ def test_every_kernel_instance_matches_oracle(shape):
     eng.close()
 
 
-def test_model_without_ffn_blocks_uses_fallback_instance():
-    """L = 0 (no residual blocks): FOLD2 cannot peel a first block; the library must pick the FOLD-only instance."""
+@pytest.mark.parametrize("kw,split", [(dict(D=32, de=64, dh=96), False), (dict(D=128, de=None, dh=256), False),
+                                      (dict(D=128, de=None, dh=256), True), (dict(D=128, de=384, dh=384), False)],
+                         ids=["test-shape", "occ2-shape", "occ2-shape-split", "C2-shape"])
+def test_model_without_ffn_blocks(kw, split):
+    """L = 0 (no residual blocks): FOLD2 / the split form peel a first block that does not exist.  The library runs such a
+    model as L = 1 with an all-zero block (z + W_down relu(W_up z) = z exactly), on every kernel form -- the round-2 fallback
+    to a FOLD-only instance did not exist for the two-workgroups-per-CU shapes."""
     from qinco_amd import QincoConfig, QincoEngine, synth_state_dict, synth_vectors
-    cfg = QincoConfig(D=32, M=3, K=256, L=0, de=64, dh=96, A=8, B=2)
+    cfg = QincoConfig(M=3, K=256, L=0, A=8, B=2, **kw)
     sd = synth_state_dict(cfg, 5)
     x = synth_vectors(cfg, sd, 100, seed=3)
-    eng = QincoEngine(cfg, sd, max_batch=64)
+    eng = QincoEngine(cfg, sd, max_batch=64, split_f16=split)
+    assert eng.flops_per_vector("decode") == cfg.decode_flops_per_vector()       # accounting stays the model's own L
     oracle = make_oracle(cfg, sd)
     want = oracle(x, step="encode").T
     assert_only_near_ties(oracle, x, eng.encode(x), want, NEAR_TIE, "L=0")
+    assert rel_err(eng.decode(want), oracle(want.T, step="decode")) < REL_TOL
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [None, "48,196"], ids=["production", "tile16"])
-def test_small_models_at_large_batches_are_exact_and_deterministic(variant, monkeypatch):
+@pytest.mark.parametrize("variant", [None, (48, 196)], ids=["production", "tile16"])
+def test_small_models_at_large_batches_are_exact_and_deterministic(variant):
     """Small models leave room for several workgroups per CU; the ring kernels must stay exact there (the 16-row kernel
     gave rare per-wave corruption with 3 workgroups per CU until its launch was made exclusive, csrc/mlp_inst.hip)."""
     from qinco_amd import QincoConfig, QincoEngine, synth_state_dict, synth_vectors
-    if variant:
-        monkeypatch.setenv("QINCO_MLP_VARIANT", variant)
+    diag = {"mlp_variant": variant} if variant else None
     for kw in (dict(A=0, B=1, qinco1_mode=True), dict(A=32, B=4), dict(A=8, B=4, de=64, dh=96)):
         base = dict(D=32, M=3, K=256, L=2, de=None, dh=64, qinco1_mode=False)
         base.update(kw)
@@ -450,7 +470,7 @@ def test_small_models_at_large_batches_are_exact_and_deterministic(variant, monk
         x = synth_vectors(cfg, sd, 3000, seed=999)
         oracle = make_oracle(cfg, sd)
         want = oracle(x, step="encode").T
-        eng = QincoEngine(cfg, sd, max_batch=4096)
+        eng = QincoEngine(cfg, sd, max_batch=4096, diagnostics=diag)
         runs = [eng.encode(x, return_xhat=True) for _ in range(3)]
         for codes, xhat in runs:
             assert np.array_equal(codes, runs[0][0]) and np.array_equal(xhat, runs[0][1])
@@ -466,9 +486,9 @@ def _ivf_cfg(D, ivf_K):
 
 
 @pytest.mark.parametrize("D,ivf_K,n", [(32, 4096, 3000), (96, 2048, 1000), (128, 32768, 2500), (256, 1024, 700), (768, 2048, 300)])
-def test_ivf_fp16_filter_equals_exact_table(D, ivf_K, n, monkeypatch):
+def test_ivf_fp16_filter_equals_exact_table(D, ivf_K, n):
     """The fp16-filter + exact-candidates assignment against numpy's argmin of the reference formula and against the
-    fp32 table kernel alone (QINCO_IVF_FP32=1): equal wherever the two best distances are not a rounding-level tie."""
+    fp32 table kernel alone (QINCO_CREATE_IVF_FP32): equal wherever the two best distances are not a rounding-level tie."""
     from oracle.qinco_oracle import approx_pairwise_distance
     from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
     cfg = _ivf_cfg(D, ivf_K)
@@ -479,8 +499,7 @@ def test_ivf_fp16_filter_equals_exact_table(D, ivf_K, n, monkeypatch):
     st = eng.ivf_last_stats()
     assert not st["fell_back"] and n <= st["candidates"] < 24 * n, st   # ~8 per vector: the threshold comes from a 1/8 sample
     eng.close()
-    monkeypatch.setenv("QINCO_IVF_FP32", "1")
-    eng32 = QincoEngine(cfg, sd, max_batch=4096)
+    eng32 = QincoEngine(cfg, sd, max_batch=4096, diagnostics={"ivf_fp32": True})
     got32 = eng32.encode(x)[:, 0]
     assert eng32.ivf_last_stats() == {"candidates": 0, "fell_back": False}
     eng32.close()
@@ -493,7 +512,7 @@ def test_ivf_fp16_filter_equals_exact_table(D, ivf_K, n, monkeypatch):
     assert (got != got32).sum() <= (~clear).sum()
 
 
-def test_ivf_fp16_filter_falls_back_on_ties_and_range(monkeypatch):
+def test_ivf_fp16_filter_falls_back_on_ties_and_range():
     """Duplicated centroids make every copy a candidate (the list overflows) and huge inputs leave the fp16 range: both
     must take the exact fp32 kernel and still give argmin with the lowest index among exact ties."""
     from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
@@ -515,8 +534,7 @@ def test_ivf_fp16_filter_falls_back_on_ties_and_range(monkeypatch):
     xbig[7, 3] = 1.0e7 * float(sd2["data_std"])       # normalised value far outside the fp16 range
     got2 = eng2.encode(xbig)[:, 0]
     assert eng2.ivf_last_stats()["fell_back"]
-    monkeypatch.setenv("QINCO_IVF_FP32", "1")
-    eng3 = QincoEngine(cfg, sd2, max_batch=1024)
+    eng3 = QincoEngine(cfg, sd2, max_batch=1024, diagnostics={"ivf_fp32": True})
     assert np.array_equal(got2, eng3.encode(xbig)[:, 0])
     eng2.close()
     eng3.close()
@@ -526,8 +544,7 @@ def test_model_exposes_inner_model_attribute_path():
     """search_tasks.py:449 reads model.qinco_model.steps[0].ivf_centroids.weight on the inference wrapper."""
     from qinco_amd import synth_state_dict
     from qinco_amd.model import QINCoHIP
-    cfg, seed = golden_cases()["tiny_ivf_beam"]
-    sd = synth_state_dict(cfg, seed)
+    cfg, sd = golden_model("tiny_ivf_beam")
     model = QINCoHIP(cfg, sd, max_batch=64)
     w = model.qinco_model.steps[0].ivf_centroids.weight
     assert tuple(w.shape) == (cfg.ivf_K, cfg.D) and np.array_equal(np.asarray(w), sd["steps.0.ivf_centroids.weight"])
@@ -586,14 +603,40 @@ def test_from_checkpoint_runs_encode_database_on_the_gpu(tmp_path):
     assert_only_near_ties(og, db[:200], greedy(db[:200], step="encode").T, og(db[:200], step="encode").T, NEAR_TIE, "B=1")
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_f16"])
+@pytest.mark.parametrize("name", ["trained_qinco2S", "trained_qinco1"])
+def test_reference_trained_checkpoint_through_from_checkpoint(name, split):
+    """A checkpoint the imported reference TRAINED (tests/golden/make_trained.py) and wrote with its own save_model, loaded
+    through the product's checkpoint reader and run behind the reference-shaped model object -- uint8 rows for the
+    BigANN-like one -- against what the reference itself produced from the same file."""
+    from conftest import GOLDEN
+    from cases import CASES
+    from qinco_amd.model import QINCoHIP
+    g = load_golden(name)
+    model = QINCoHIP.from_checkpoint(str(GOLDEN / CASES[name].ckpt), max_batch=100, split_f16=split)
+    assert model.built and model.engine.split_f16 == split
+    if name == "trained_qinco2S":
+        assert g["x"].dtype == np.uint8
+    codes = np.ascontiguousarray(model(g["x"], step="encode").T)
+    want = ref_codes(g)
+    bad = np.nonzero((codes != want).any(axis=1))[0]
+    print(f"{name} split={split}: {len(bad)} of {len(want)} rows differ from the reference's")
+    if len(bad):
+        oracle = make_oracle(*golden_model(name))
+        assert_only_near_ties(oracle, g["x"], codes, want, NEAR_TIE, f"{name} split={split}")
+    ok = np.setdiff1d(np.arange(len(want)), bad)
+    assert rel_err(model(codes.T, step="decode")[ok], g["decoded"][ok]) < REL_TOL
+    assert rel_err(model(g["rand_codes"].T, step="decode"), g["rand_decoded_base"]) < REL_TOL
+    model.engine.close()
+
+
 def test_split_f16_model_object_through_encode_database(tmp_path):
     """The opt-in form behind the reference-shaped model object: QINCoHIP(split_f16=True) -> encode_database (part file) ->
     EncodedDBIterator -> decode, against the reference golden of the same model."""
     from qinco_amd import synth_state_dict
     from qinco_amd.encode_db import EncodedDBIterator, encode_database
     from qinco_amd.model import QINCoHIP
-    cfg, seed = golden_cases()["tiny_proj_dh128"]
-    sd = synth_state_dict(cfg, seed)
+    cfg, sd = golden_model("tiny_proj_dh128")
     g = load_golden("tiny_proj_dh128")
     model = QINCoHIP(cfg, sd, max_batch=100, split_f16=True)
     assert model.engine.split_f16
@@ -637,8 +680,7 @@ def test_nan_input_on_the_ivf_path_stays_in_range():
     """A NaN vector has no nearest centroid (every comparison is false): the coarse code must stay a valid index (argmin of
     NaNs = 0 in the reference) instead of -1 / an out-of-bounds gather."""
     from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
-    cfg, seed = golden_cases()["tiny_ivf_beam"]
-    sd = synth_state_dict(cfg, seed)
+    cfg, sd = golden_model("tiny_ivf_beam")
     eng = QincoEngine(cfg, sd, max_batch=256)
     x = synth_vectors(cfg, sd, 40, seed=2)
     clean = eng.encode(x)
@@ -650,13 +692,13 @@ def test_nan_input_on_the_ivf_path_stays_in_range():
     eng.close()
 
 
-def _stress_worker(wl, n, out):
+def _stress_worker(wl, n, out, variant=None):
     from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
     from qinco_amd.config import BASELINE_CONFIGS
     cfg = BASELINE_CONFIGS[wl]
     sd = synth_state_dict(cfg, 1236)
     x = synth_vectors(cfg, sd, n, seed=123)
-    eng = QincoEngine(cfg, sd, max_batch=8192)
+    eng = QincoEngine(cfg, sd, max_batch=8192, diagnostics={"mlp_variant": variant} if variant else None)
     c1, h1 = eng.encode(x, return_xhat=True)
     c2, h2 = eng.encode(x, return_xhat=True)
     assert np.array_equal(c1, c2) and np.array_equal(h1, h2), "run-to-run nondeterminism"
@@ -675,23 +717,31 @@ def test_weight_delivery_variants_agree_bitwise(wl, tmp_path):
     n = 16384
     res = {}
     for var in ["", "48,92", "48,76", "36,12", "8,0"]:
-        env = dict(os.environ)
-        env.pop("QINCO_MLP_VARIANT", None)
-        if var:
-            env["QINCO_MLP_VARIANT"] = var
         out = str(tmp_path / f"v_{var.replace(',', '_')}.npz")
+        vt = tuple(int(v) for v in var.split(",")) if var else None
         code = (f"import sys; sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(ROOT / 'tests')!r}); "
-                f"from test_hip_parity import _stress_worker; _stress_worker({wl!r}, {n}, {out!r})")
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+                f"from test_hip_parity import _stress_worker; _stress_worker({wl!r}, {n}, {out!r}, {vt!r})")
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
         res[var or "production"] = dict(np.load(out))
     base = res["48,76"]
     for k in ("36,12", "8,0"):
         assert np.array_equal(res[k]["codes"], base["codes"]) and np.array_equal(res[k]["xhat"], base["xhat"]), k
+    from qinco_amd import synth_state_dict, synth_vectors
+    from qinco_amd.config import BASELINE_CONFIGS
+    cfg = BASELINE_CONFIGS[wl]
+    sd = synth_state_dict(cfg, 1236)
+    x = synth_vectors(cfg, sd, n, seed=123)        # = _stress_worker's inputs
+    oracle = make_oracle(cfg, sd)
     for k in ("production", "48,92"):
-        diff = int((res[k]["codes"] != base["codes"]).any(axis=1).sum())
-        print(f"{wl}: {k} (folded head) vs unfolded: {diff} of {n} code rows differ")
-        assert diff <= n // 1000
+        bad = np.nonzero((res[k]["codes"] != base["codes"]).any(axis=1))[0]
+        print(f"{wl}: {k} (folded head) vs unfolded: {len(bad)} of {n} code rows differ")
+        assert len(bad) <= n // 1000
+        sel = bad[:12]                              # the margin rule against the oracle on (up to) a dozen of them
+        if len(sel):
+            want = oracle(x[sel], step="encode").T
+            assert_only_near_ties(oracle, x[sel], res[k]["codes"][sel], want, NEAR_TIE, f"{wl} {k}")
+            assert_only_near_ties(oracle, x[sel], base["codes"][sel], want, NEAR_TIE, f"{wl} unfolded")
 
 
 def test_device_selftest_of_sort_and_selection_primitives():

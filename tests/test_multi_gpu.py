@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, golden_cases
+from conftest import ROOT, golden_model
 
 pytestmark = pytest.mark.gpu
 
@@ -38,8 +38,7 @@ def _run_ranks(world, outdir, backend, n, dev_input=False):
 def _single_process_codes(n):
     from qinco_amd import synth_state_dict, synth_vectors
     from qinco_amd.model import QINCoHIP
-    cfg, seed = golden_cases()["tiny_proj_beam"]
-    sd = synth_state_dict(cfg, seed)
+    cfg, sd = golden_model("tiny_proj_beam")
     model = QINCoHIP(cfg, sd, max_batch=256)
     want = model(synth_vectors(cfg, sd, n, seed=4), step="encode").T
     model.engine.close()

@@ -7,7 +7,7 @@ Recalls must be equal."""
 import numpy as np
 import pytest
 
-from conftest import golden_cases, load_golden
+from conftest import golden_model, load_golden
 
 REL = 2e-5
 
@@ -43,8 +43,7 @@ def test_oracle_search_pipeline_reproduces_reference_reconstructions():
     from conftest import make_oracle
     from qinco_amd import synth_state_dict
     g = load_golden("search_small_db")
-    cfg, seed = golden_cases()["tiny_proj_beam"]
-    o = make_oracle(cfg, synth_state_dict(cfg, seed))
+    o = make_oracle(*golden_model("tiny_proj_beam"))
     n = 512
     xhat = o(o(g["db"][:n], step="encode"), step="decode")
     rel = np.abs(xhat - g["xhat"][:n]).max(axis=1) / np.abs(g["xhat"][:n]).max()
@@ -182,8 +181,8 @@ def test_search_small_db_pipeline_and_compute_mse_on_gpu():
     from qinco_amd.model import QINCoHIP
     from qinco_amd.search import search_small_db
     g = load_golden("search_small_db")
-    cfg, seed = golden_cases()["tiny_proj_beam"]
-    model = QINCoHIP(cfg, synth_state_dict(cfg, seed), max_batch=1024)
+    cfg, sd_ = golden_model("tiny_proj_beam")
+    model = QINCoHIP(cfg, sd_, max_batch=1024)
     res = search_small_db(model, g["db"], g["queries"], g["gt"], batch=1024)
     xhat = res["xhat"].cpu().numpy()
     same = np.abs(xhat - g["xhat"]).max(axis=1) <= 1e-5 * np.abs(g["xhat"]).max()

@@ -394,6 +394,8 @@ def main():
         pad = torch.zeros((longest, cfg.M_total), dtype=torch.uint8, device=dev)
         pad[: len(mine)] = mine
         try:
+            if os.environ.get("QINCO_BENCH_FORCE_GATHER_ERROR"):      # test hook (tests/test_multi_gpu.py): the fail-soft path
+                raise RuntimeError("forced by QINCO_BENCH_FORCE_GATHER_ERROR")
             if data_group is not None:
                 bucket = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
                 dist.gather(pad, bucket, dst=0, group=data_group)

@@ -38,7 +38,7 @@ typedef enum {
   QINCO_OK = 0,
   QINCO_ERR_INVALID = -1,      /* bad argument / unsupported hyper-parameters (reference: assert / ValueError) */
   QINCO_ERR_HIP = -2,          /* HIP runtime failure */
-  QINCO_ERR_UNSUPPORTED = -3,  /* (D, De, Dh) has no compiled kernel instance */
+  QINCO_ERR_UNSUPPORTED = -3,  /* (D, De, Dh) has no kernel instance (compiled in or loaded: qinco_load_instance) */
   QINCO_ERR_RANGE = -4         /* a code >= K was passed to decode (reference: index error) */
 } qinco_status;
 
@@ -159,8 +159,19 @@ QINCO_API int qinco_ivf_last_stats(qinco_handle h, int64_t* candidates, int32_t*
  * Writes at most `cap` bytes including the terminator; returns the length the full text needs. */
 QINCO_API int qinco_describe(qinco_handle h, char* buf, int32_t cap);
 
-/* 1 if a fused-MLP kernel instance exists for (D, De, Dh). */
+/* Model geometry.  The reference builds any (D, de, dh) (qinco/model/qinco_base.py:229-260).  The kernels work on 32-feature
+ * blocks: qinco_create zero-pads every tensor of another geometry up to the next multiple of 32 (padding features are exact
+ * zeros and contribute exact zeros; a model with in/out projections keeps De != D), and looks for a fused-MLP kernel instance of
+ * the padded shape -- compiled in (csrc/shapes.def: every preset of the reference on every dataset dimension) or loaded:
+ *   qinco_padded_shape   out3 = {D, De, Dh} as the kernels will see them
+ *   qinco_shape_supported  1 if an instance for the padded shape exists right now
+ *   qinco_load_instance  register the instance in the shared object `path`: ONE translation unit of csrc/mlp_inst.hip built
+ *                        with -DQD= -DQDE= -DQDH= -DQP= -DQVAR= -DQINCO_INSTANCE_MODULE (hipcc -shared --offload-arch=gfx950;
+ *                        the Python host does this on demand: qinco_amd.build.ensure_instance).  Loaded instances stay for the
+ *                        life of the process.  QINCO_ERR_INVALID if the file cannot be loaded or was built from other sources. */
 QINCO_API int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh);
+QINCO_API int qinco_padded_shape(int32_t D, int32_t De, int32_t Dh, int32_t* out3);
+QINCO_API int qinco_load_instance(const char* path);
 
 /* ---- look-up decoders downstream of the hot path --------------------------------------------
  * out[n] = sum_j tables[j][ codes[n][a[j]] * mul + (b[j] >= 0 ? codes[n][b[j]] : 0) ]   (fp32, summed in j order)

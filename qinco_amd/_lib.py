@@ -15,7 +15,7 @@ CREATE_SPLIT_F16, CREATE_IVF_FP32, CREATE_TABLE_VALU, CREATE_DECODE_FOLDED, CREA
 
 # every symbol include/qinco_hip.h declares (tests check the library exports all of them)
 API_SYMBOLS = [
-    "qinco_create", "qinco_create_ex", "qinco_create_opt", "qinco_describe", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
+    "qinco_create", "qinco_create_ex", "qinco_create_opt", "qinco_describe", "qinco_padded_shape", "qinco_load_instance", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
     "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
     "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
@@ -94,6 +94,10 @@ def load() -> C.CDLL:
     lib.qinco_create_ex.argtypes = [C.POINTER(QincoDesc), C.POINTER(QincoWeights), C.c_int32, C.POINTER(vp)]
     lib.qinco_create_opt.argtypes = [C.POINTER(QincoDesc), C.POINTER(QincoWeights), C.POINTER(QincoOptions), C.POINTER(vp)]
     lib.qinco_create_opt.restype = C.c_int
+    lib.qinco_padded_shape.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    lib.qinco_padded_shape.restype = C.c_int
+    lib.qinco_load_instance.argtypes = [C.c_char_p]
+    lib.qinco_load_instance.restype = C.c_int
     lib.qinco_describe.argtypes = [vp, C.c_char_p, C.c_int32]
     lib.qinco_describe.restype = C.c_int
     lib.qinco_destroy.argtypes = [vp]

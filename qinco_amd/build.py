@@ -18,6 +18,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OBJ = PKG / "_build"
 LIB = PKG / "libqinco_hip.so"
+INST = PKG / "_instances"      # kernel instances built on demand (ensure_instance); travels to the GPU box, not into git
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden"]
@@ -111,6 +112,48 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
         if verbose:
             print(f"[qinco_amd.build] linked {LIB}", file=sys.stderr)
     return LIB
+
+
+def instance_plan(Dp: int, Dep: int, Dhp: int) -> tuple[int, int]:
+    """(P, VAR) of the kernel form that serves a padded shape (csrc/shapes.def explains the VAR bits): the 32-row kernel with the
+    folded head -- two workgroups per CU on the short shapes -- while its activations fit the register file (De, Dh <= 384),
+    else the 16-row tile kernel."""
+    if Dep <= 384 and Dhp <= 384:
+        return (48, 380) if (Dep <= 128 and Dhp <= 256) else (48, 124)
+    if Dep <= 768 and max(Dep, Dhp) <= 1024:
+        return (48, 196)
+    raise NotImplementedError(f"no kernel form for De={Dep}, Dh={Dhp}: the 16-row tile kernel holds De/4 + max(De, Dh)/4 registers "
+                              "of activations per lane (De <= 768, Dh <= 1024)")
+
+
+def ensure_instance(D: int, De: int, Dh: int, verbose: bool = False) -> Path | None:
+    """Make sure the loaded libqinco_hip.so has a fused-MLP kernel instance for a model geometry, building one on demand.
+
+    The library is asked for the padded shape (qinco_padded_shape) and whether it is served already (shapes.def lists every
+    preset of the reference; qinco_shape_supported).  If not, ONE translation unit of csrc/mlp_inst.hip is compiled for that
+    shape into qinco_amd/_instances/inst_<shape>.so (about a minute; cached by shape, rebuilt when the kernel sources change) and
+    registered with qinco_load_instance.  Returns the module's path, or None when nothing had to be loaded.
+    Needs hipcc on the machine the first time a shape is seen; raises RuntimeError with that message otherwise."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    out3 = (C.c_int32 * 3)()
+    _lib.check(lib.qinco_padded_shape(D, De, Dh, out3))
+    if lib.qinco_shape_supported(D, De, Dh):
+        return None
+    Dp, Dep, Dhp = (int(v) for v in out3)
+    P, var = instance_plan(Dp, Dep, Dhp)
+    INST.mkdir(exist_ok=True)
+    so = INST / f"inst_{Dp}_{Dep}_{Dhp}_{P}_{var}.so"
+    cmd = [c for c in instance_cmd("hipcc", (Dp, Dep, Dhp, P, var), so, extra=("-DQINCO_INSTANCE_MODULE", "-shared")) if c != "-c"]
+    if not _fresh(so, cmd[1:]):
+        cmd[0] = hipcc()          # raises when there is no compiler: a new geometry cannot be served on this machine
+        if verbose:
+            print(f"[qinco_amd.build] compiling a kernel instance for ({Dp}, {Dep}, {Dhp}) [model ({D}, {De}, {Dh})]", file=sys.stderr)
+        _run([*cmd, "-MD", "-MF", str(so.with_suffix(".d"))])
+        so.with_suffix(".cmd").write_text(" ".join(cmd[1:]))
+    _lib.check(lib.qinco_load_instance(str(so).encode()))
+    return so
 
 
 if __name__ == "__main__":

@@ -300,12 +300,15 @@ __global__ void __launch_bounds__(64) selftest_select_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 __global__ void normalize_kernel(const void* __restrict__ x, int x_dtype, long row_stride_bytes,
                                  const float* __restrict__ mean, float std_, float* __restrict__ out,
-                                 long n, int D) {
+                                 long n, int D, int Dp) {
+  // D = the model's data dimension (columns of x), Dp >= D = the kernels' padded dimension (columns of out; the padding
+  // features are exact zeros in the input, the codebooks and the weights, so they contribute exact zeros everywhere)
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = n * D;
+  long total = n * Dp;
   for (; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    long r = idx / D;
-    int d = (int)(idx - r * D);
+    long r = idx / Dp;
+    int d = (int)(idx - r * Dp);
+    if (d >= D) { out[idx] = 0.f; continue; }
     const char* rowp = reinterpret_cast<const char*>(x) + r * row_stride_bytes;
     float v = x_dtype == 0 ? reinterpret_cast<const float*>(rowp)[d]
                            : (float)reinterpret_cast<const unsigned char*>(rowp)[d];
@@ -314,13 +317,16 @@ __global__ void normalize_kernel(const void* __restrict__ x, int x_dtype, long r
 }
 
 // x = xhat * std + mean  (qinco_inference.py:281): two roundings (no fma contraction), like ATen mul + add.
+// xhat rows are Dp floats apart, out rows D.
 __global__ void denormalize_kernel(const float* __restrict__ xhat, const float* __restrict__ mean,
-                                   float std_, float* __restrict__ out, long n, int D) {
+                                   float std_, float* __restrict__ out, long n, int D, int Dp) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = n * D;
   for (; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    int d = (int)(idx % D);
-    out[idx] = mean ? __fadd_rn(__fmul_rn(xhat[idx], std_), mean[d]) : xhat[idx];
+    long r = idx / D;
+    int d = (int)(idx - r * D);
+    const float v = xhat[r * Dp + d];
+    out[idx] = mean ? __fadd_rn(__fmul_rn(v, std_), mean[d]) : v;
   }
 }
 

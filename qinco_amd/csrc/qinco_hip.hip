@@ -9,8 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
+
+#include <dlfcn.h>
 
 #include "abi_util.hpp"
 #include "aux_kernels.hpp"
@@ -39,14 +42,33 @@ static const MlpInstance g_instances[] = {
 #undef QINCO_SHAPE
 };
 
+// Instances built on demand for geometries shapes.def does not list (qinco_load_instance): each lives in a shared object of
+// its own -- one translation unit of csrc/mlp_inst.hip with its shape as -D flags -- and is never unloaded.  A deque: element
+// addresses handed out to handles stay valid when more instances are loaded.
+static std::deque<MlpInstance> g_loaded;
+
 const MlpInstance* find_mlp_instance(int D, int De, int Dh, int want_P, int want_var) {
   const MlpInstance* first = nullptr;
-  for (const MlpInstance& i : g_instances) {
-    if (i.D != D || i.De != De || i.Dh != Dh) continue;
+  auto visit = [&](const MlpInstance& i) -> const MlpInstance* {
+    if (i.D != D || i.De != De || i.Dh != Dh) return nullptr;
     if (!first) first = &i;
-    if (i.P == want_P && i.var == want_var) return &i;
-  }
+    return (i.P == want_P && i.var == want_var) ? &i : nullptr;
+  };
+  for (const MlpInstance& i : g_instances)
+    if (const MlpInstance* hit = visit(i)) return hit;
+  for (const MlpInstance& i : g_loaded)
+    if (const MlpInstance* hit = visit(i)) return hit;
   return first;
+}
+
+// The kernels work on 32-feature blocks.  Any other geometry is zero-padded up to the next multiple of 32 when the weights are
+// packed: padding features are exact zeros in the inputs, codebooks and weights, so they add exact zeros to every sum.  A model
+// WITH in/out projections (De != D) must keep them after padding (the kernels read "De == D" as "identity projections").
+static void padded_geometry(int D, int De, int Dh, int* Dp, int* Dep, int* Dhp) {
+  *Dp = round_up(D, 32);
+  *Dep = round_up(De, 32);
+  *Dhp = round_up(Dh, 32);
+  if (De != D && *Dep == *Dp) *Dep += 32;
 }
 }  // namespace qinco
 
@@ -70,11 +92,11 @@ int qinco::abi_fail(int code, const char* fmt, ...) {
 // handle
 // ---------------------------------------------------------------------------------------------
 struct qinco_handle_s {
-  qinco_desc d{};
+  qinco_desc d{};      // the geometry the kernels run (D, De, Dh padded to multiples of 32; L >= 1)
+  qinco_desc user{};   // the model's own hyper-parameters: I/O row widths and FLOP accounting
   int device = 0;
   int A = 0, B = 1;  // active search widths
   const MlpInstance* inst = nullptr;
-  int L_alg = 0;   // the model's own L (d.L is 1 for an L = 0 model: it runs with one all-zero block); FLOP accounting only
   StreamDims sd{};
 
   float* mean = nullptr;
@@ -120,6 +142,7 @@ struct qinco_handle_s {
   int64_t cap_n = 0;
   int cap_A = -1, cap_B = -1;
   size_t beam_lds_max = 0;   // dynamic LDS already granted to beam_select_kernel
+  size_t table_lds_max = 0;  // ... and to dist_topk_kernel
   float* xn = nullptr;
   float* xhat[2] = {nullptr, nullptr};
   int* hist[2] = {nullptr, nullptr};
@@ -165,8 +188,8 @@ static int n_codes(const qinco_handle_s* h, int m) {
 
 static double mlp_flops_per_row(const qinco_handle_s* h) {
   // R_mlp = [De != D] 4 D De + 2 (De + D) De + 4 L De Dh
-  const qinco_desc& d = h->d;
-  double f = 2.0 * (d.De + d.D) * d.De + 4.0 * h->L_alg * (double)d.De * d.Dh;
+  const qinco_desc& d = h->user;
+  double f = 2.0 * (d.De + d.D) * d.De + 4.0 * d.L * (double)d.De * d.Dh;
   if (d.De != d.D) f += 4.0 * d.D * d.De;
   return f;
 }
@@ -579,8 +602,108 @@ static int ensure_decode_scratch(qinco_handle_s* h, int64_t n) {
 // create / destroy
 // ---------------------------------------------------------------------------------------------
 extern "C" int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh) {
-  return find_mlp_instance(D, De, Dh, -1, -1) != nullptr;
+  if (D <= 0 || De <= 0 || Dh <= 0) return 0;
+  int Dp, Dep, Dhp;
+  padded_geometry(D, De, Dh, &Dp, &Dep, &Dhp);
+  return find_mlp_instance(Dp, Dep, Dhp, -1, -1) != nullptr;
 }
+
+extern "C" int qinco_padded_shape(int32_t D, int32_t De, int32_t Dh, int32_t* out3) {
+  if (!out3 || D <= 0 || De <= 0 || Dh <= 0) return fail(QINCO_ERR_INVALID, "qinco_padded_shape: bad argument");
+  int Dp, Dep, Dhp;
+  padded_geometry(D, De, Dh, &Dp, &Dep, &Dhp);
+  out3[0] = Dp;
+  out3[1] = Dep;
+  out3[2] = Dhp;
+  return QINCO_OK;
+}
+
+extern "C" int qinco_load_instance(const char* path) {
+  if (!path) return fail(QINCO_ERR_INVALID, "qinco_load_instance: null path");
+  void* so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!so) return fail(QINCO_ERR_INVALID, "qinco_load_instance: %s", dlerror());
+  typedef int (*info_fn)(int32_t*, void**);
+  info_fn info = reinterpret_cast<info_fn>(dlsym(so, "qinco_instance_info"));
+  if (!info) {
+    dlclose(so);
+    return fail(QINCO_ERR_INVALID, "qinco_load_instance: %s does not export qinco_instance_info (not built from csrc/mlp_inst.hip "
+                                   "with -DQINCO_INSTANCE_MODULE?)", path);
+  }
+  int32_t v[6] = {0, 0, 0, 0, 0, 0};
+  void* fns[2] = {nullptr, nullptr};
+  const int abi = info(v, fns);
+  if (abi != (int)sizeof(MlpArgs) || !fns[0] || !fns[1]) {
+    dlclose(so);
+    return fail(QINCO_ERR_INVALID, "qinco_load_instance: %s was built against another version of csrc/mlp_args.hpp (%d vs %d)", path, abi,
+                (int)sizeof(MlpArgs));
+  }
+  for (const MlpInstance& i : g_loaded)
+    if (i.D == v[0] && i.De == v[1] && i.Dh == v[2] && i.P == v[3] && i.var == v[4]) return QINCO_OK;   // already there
+  g_loaded.push_back(MlpInstance{v[0], v[1], v[2], v[3], v[4], reinterpret_cast<mlp_launch_fn>(fns[0]),
+                                 reinterpret_cast<xproj_launch_fn>(fns[1])});
+  return QINCO_OK;
+}
+
+// Zero-padded copies of a model's tensors for a geometry that is not made of 32-feature blocks (padded_geometry).
+struct PaddedWeights {
+  std::deque<std::vector<float>> store;
+  std::vector<const float*> cb, sub, inp, outp, cw, cbias, up, down;
+  qinco_weights w{};
+
+  const float* pad2d(const float* src, long rows, int cols, long rows_p, int cols_p) {
+    if (!src) return nullptr;
+    store.emplace_back((size_t)rows_p * cols_p, 0.f);
+    float* dst = store.back().data();
+    for (long r = 0; r < rows; ++r) std::memcpy(dst + (size_t)r * cols_p, src + (size_t)r * cols, (size_t)cols * sizeof(float));
+    return dst;
+  }
+  // returns nullptr, or what is missing
+  const char* build(const qinco_desc& d, const qinco_weights& u, int Dp, int Dep, int Dhp) {
+    const int M = d.M, L = d.L, D = d.D, De = d.De, Dh = d.Dh;
+    if (!u.data_mean || !u.codebook) return "missing data_mean / codebook";
+    w = u;
+    w.data_mean = pad2d(u.data_mean, 1, D, 1, Dp);
+    cb.assign(M, nullptr);
+    sub.assign(M, nullptr);
+    inp.assign(M, nullptr);
+    outp.assign(M, nullptr);
+    cw.assign(M, nullptr);
+    cbias.assign(M, nullptr);
+    up.assign((size_t)M * (L > 0 ? L : 1), nullptr);
+    down.assign((size_t)M * (L > 0 ? L : 1), nullptr);
+    for (int m = 0; m < M; ++m) {
+      const long rows = (m == 0 && d.ivf_K > 0) ? d.ivf_K : d.K;
+      cb[m] = pad2d(u.codebook[m], rows, D, rows, Dp);
+      if (m == 0) continue;
+      if (u.sub_codebook) sub[m] = pad2d(u.sub_codebook[m], d.K, D, d.K, Dp);
+      if (u.in_proj) inp[m] = pad2d(u.in_proj[m], De, D, Dep, Dp);
+      if (u.out_proj) outp[m] = pad2d(u.out_proj[m], D, De, Dp, Dep);
+      if (u.cat_b) cbias[m] = pad2d(u.cat_b[m], 1, De, 1, Dep);
+      if (u.cat_w && u.cat_w[m]) {   // (De, De + D): the z columns and the xhat columns are padded separately
+        store.emplace_back((size_t)Dep * (Dep + Dp), 0.f);
+        float* dst = store.back().data();
+        for (int r = 0; r < De; ++r) {
+          std::memcpy(dst + (size_t)r * (Dep + Dp), u.cat_w[m] + (size_t)r * (De + D), (size_t)De * sizeof(float));
+          std::memcpy(dst + (size_t)r * (Dep + Dp) + Dep, u.cat_w[m] + (size_t)r * (De + D) + De, (size_t)D * sizeof(float));
+        }
+        cw[m] = dst;
+      }
+      for (int l = 0; l < L; ++l) {
+        if (u.up) up[(size_t)m * L + l] = pad2d(u.up[(size_t)m * L + l], Dh, De, Dhp, Dep);
+        if (u.down) down[(size_t)m * L + l] = pad2d(u.down[(size_t)m * L + l], De, Dh, Dep, Dhp);
+      }
+    }
+    w.codebook = cb.data();
+    w.sub_codebook = u.sub_codebook ? sub.data() : nullptr;
+    w.in_proj = u.in_proj ? inp.data() : nullptr;
+    w.out_proj = u.out_proj ? outp.data() : nullptr;
+    w.cat_w = u.cat_w ? cw.data() : nullptr;
+    w.cat_b = u.cat_b ? cbias.data() : nullptr;
+    w.up = u.up ? up.data() : nullptr;
+    w.down = u.down ? down.data() : nullptr;
+    return nullptr;
+  }
+};
 
 // Diagnostic knobs of a handle (qinco_options in the ABI).  Experiment builds (-DQINCO_EXPERIMENT, scripts/) also read them from
 // the environment so that an unmodified caller can be A/B-ed; the shipping library has no environment switches.
@@ -653,11 +776,22 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
     wpad.up = wpad.down = zero_ptrs.data();
     w = &wpad;
   }
-  const qinco_desc& d = dpad;
-  if (d.D <= 0 || d.De <= 0 || d.Dh <= 0 || d.M <= 0 || d.K <= 0 || d.L < 0 || d.max_batch <= 0)
+  if (desc->D <= 0 || desc->De <= 0 || desc->Dh <= 0 || desc->M <= 0 || desc->K <= 0 || desc->L < 0 || desc->max_batch <= 0)
     return fail(QINCO_ERR_INVALID, "qinco_create: non-positive hyper-parameter");
-  if (d.D % 32 || d.De % 32 || d.Dh % 32)
-    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: D, De, Dh must be multiples of 32 (got %d, %d, %d)", d.D, d.De, d.Dh);
+  // Geometry that is not a multiple of 32 (or whose projections would vanish): zero-padded copies of every tensor.
+  PaddedWeights padw;
+  {
+    int Dp, Dep, Dhp;
+    padded_geometry(desc->D, desc->De, desc->Dh, &Dp, &Dep, &Dhp);
+    if (Dp != desc->D || Dep != desc->De || Dhp != desc->Dh) {
+      if (const char* why = padw.build(dpad, *w, Dp, Dep, Dhp)) return fail(QINCO_ERR_INVALID, "qinco_create: %s", why);
+      dpad.D = Dp;
+      dpad.De = Dep;
+      dpad.Dh = Dhp;
+      w = &padw.w;
+    }
+  }
+  const qinco_desc& d = dpad;
   if (d.K > 1024) return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: K=%d > 1024 not supported", d.K);
   if (d.A < 0 || d.A > d.K || d.B < 1) return fail(QINCO_ERR_INVALID, "qinco_create: need 0 <= A <= K and B >= 1");
   if (d.ivf_K < 0 || d.ivf_K % 32 || d.ivf_K > (1 << 24))
@@ -681,8 +815,9 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
     fn = sp;
   }
   if (!fn && d.M > 1)
-    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: no fused-MLP kernel instance for (D=%d, De=%d, Dh=%d); add it to csrc/shapes.def",
-                d.D, d.De, d.Dh);
+    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: no fused-MLP kernel instance for (D=%d, De=%d, Dh=%d) [the model's (%d, %d, %d) in "
+                "32-feature blocks]: build one on demand (qinco_amd.build.ensure_instance -> qinco_load_instance) or add it to csrc/shapes.def",
+                d.D, d.De, d.Dh, desc->D, desc->De, desc->Dh);
   if (!w->data_mean || !w->codebook) return fail(QINCO_ERR_INVALID, "qinco_create: missing data_mean / codebook");
   if (d.M > 1 && (!w->cat_w || !w->cat_b || (d.L > 0 && (!w->up || !w->down))))
     return fail(QINCO_ERR_INVALID, "qinco_create: missing MLP weights");
@@ -693,7 +828,7 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
 
   qinco_handle_s* h = new qinco_handle_s();
   h->d = d;
-  h->L_alg = desc->L;
+  h->user = *desc;
   h->A = d.A;
   h->B = d.B;
   h->inst = fn;
@@ -984,6 +1119,11 @@ static int launch_dist_topk(qinco_handle_s* h, const float* x, const float* xhat
     return 0;
   }
   size_t lds = ((size_t)DT_TG * d.D + 256 * DT_CP + (size_t)DT_TG * d.K + DT_TG) * sizeof(float);
+  if (lds > 160 * 1024) return fail(QINCO_ERR_UNSUPPORTED, "pre-selection table: D=%d, K=%d do not fit the 160 KiB of LDS", d.D, d.K);
+  if (lds > 64 * 1024 && lds > h->table_lds_max) {   // above the default dynamic-LDS limit (wide D without an MFMA table instance)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dist_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->table_lds_max = lds;
+  }
   unsigned grid = (unsigned)((G + DT_TG - 1) / DT_TG);
   hipLaunchKernelGGL(dist_topk_kernel, dim3(grid), dim3(256), lds, st, x, xhat, F, cb, cn, d.K, d.D, G, T, ids);
   HIP_TRY(hipGetLastError());
@@ -1084,7 +1224,7 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
   const qinco_desc& d = h->d;
   const int A = h->A, B = h->B, K = d.K, D = d.D, M = d.M;
   hipLaunchKernelGGL(normalize_kernel, dim3(ew_grid(n * D)), dim3(256), 0, st, x, x_dtype, (long)stride,
-                     (flags & QINCO_FLAG_NORMALISED) ? (const float*)nullptr : h->mean, h->std_, h->xn, (long)n, D);
+                     (flags & QINCO_FLAG_NORMALISED) ? (const float*)nullptr : h->mean, h->std_, h->xn, (long)n, h->user.D, D);
   HIP_TRY(hipGetLastError());
   // step 0: plain codebook, beam_0 = min(B, K0), or 1 with IVF (qinco_inference.py:237-246); a single-step model
   // ends at F = 1
@@ -1147,7 +1287,7 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
   HIP_TRY(hipGetLastError());
   if (xhat_out) {
     // F == 1 here for M > 1; for M == 1 beam 0 of each vector
-    HIP_TRY(hipMemcpy2DAsync(xhat_out, (size_t)D * 4, h->xhat[cur], (size_t)F * D * 4, (size_t)D * 4, (size_t)n,
+    HIP_TRY(hipMemcpy2DAsync(xhat_out, (size_t)h->user.D * 4, h->xhat[cur], (size_t)F * D * 4, (size_t)h->user.D * 4, (size_t)n,
                              hipMemcpyDeviceToDevice, st));
   }
   return 0;
@@ -1172,15 +1312,15 @@ extern "C" int qinco_encode(qinco_handle h, const void* x, int x_dtype, int64_t 
   HIP_TRY(hipSetDevice(h->device));  // a handle is bound to the device it was created on
   if (x_dtype != QINCO_X_F32 && x_dtype != QINCO_X_U8) return fail(QINCO_ERR_INVALID, "qinco_encode: bad x dtype %d", x_dtype);
   const size_t esz = x_dtype == QINCO_X_F32 ? 4 : 1;
-  if (stride == 0) stride = (int64_t)(h->d.D * esz);
-  if (stride < (int64_t)(h->d.D * esz)) return fail(QINCO_ERR_INVALID, "qinco_encode: row stride smaller than a row");
+  if (stride == 0) stride = (int64_t)(h->user.D * esz);
+  if (stride < (int64_t)(h->user.D * esz)) return fail(QINCO_ERR_INVALID, "qinco_encode: row stride smaller than a row");
   if ((rc = ensure_scratch(h))) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   for (int64_t i0 = 0; i0 < n; i0 += h->d.max_batch) {
     int64_t nb = n - i0 < h->d.max_batch ? n - i0 : h->d.max_batch;
     const char* xp = reinterpret_cast<const char*>(x) + i0 * stride;
     char* cp = reinterpret_cast<char*>(codes_out) + (size_t)i0 * h->d.M * code_size(code_dtype);
-    float* xo = xhat_out ? xhat_out + (size_t)i0 * h->d.D : nullptr;
+    float* xo = xhat_out ? xhat_out + (size_t)i0 * h->user.D : nullptr;
     if ((rc = encode_chunk(h, xp, x_dtype, stride, nb, cp, code_dtype, xo, flags, st))) return rc;
   }
   return QINCO_OK;
@@ -1217,7 +1357,7 @@ static int decode_chunk(qinco_handle_s* h, const void* codes, int code_dtype, in
     cur ^= 1;
   }
   hipLaunchKernelGGL(denormalize_kernel, dim3(ew_grid(n * D)), dim3(256), 0, st, h->dxhat[cur],
-                     (flags & QINCO_FLAG_NORMALISED) ? (const float*)nullptr : h->mean, h->std_, out, (long)n, D);
+                     (flags & QINCO_FLAG_NORMALISED) ? (const float*)nullptr : h->mean, h->std_, out, (long)n, h->user.D, D);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1232,7 +1372,7 @@ extern "C" int qinco_decode(qinco_handle h, const void* codes, int code_dtype, i
   for (int64_t i0 = 0; i0 < n; i0 += h->dec_cap) {
     int64_t nb = n - i0 < h->dec_cap ? n - i0 : h->dec_cap;
     const char* cp = reinterpret_cast<const char*>(codes) + (size_t)i0 * h->d.M * code_size(code_dtype);
-    if ((rc = decode_chunk(h, cp, code_dtype, nb, out + (size_t)i0 * h->d.D, flags, st))) return rc;
+    if ((rc = decode_chunk(h, cp, code_dtype, nb, out + (size_t)i0 * h->user.D, flags, st))) return rc;
   }
   return QINCO_OK;
 }
@@ -1260,7 +1400,7 @@ extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int
   if (n == 0) return QINCO_OK;
   HIP_TRY(hipSetDevice(h->device));
   const size_t esz = x_dtype == QINCO_X_F32 ? 4 : 1;
-  const size_t rowb = (size_t)h->d.D * esz;
+  const size_t rowb = (size_t)h->user.D * esz;
   if (stride == 0) stride = (int64_t)rowb;
   if (stride < (int64_t)rowb) return fail(QINCO_ERR_INVALID, "qinco_encode_host: row stride smaller than a row");
   // staged in passes of max_batch rows, so a whole database (search_tasks.py:107-116 feeds 1e9 rows) never has to
@@ -1272,7 +1412,7 @@ extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int
   if (h->split16) HIP_TRY(hipMemset(h->err_flag, 0, sizeof(int)));
   if ((rc = ensure_stage(&h->stage_x, &h->stage_x_bytes, (size_t)cap * rowb))) return rc;
   if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, (size_t)cap * crow))) return rc;
-  if (xhat_out && (rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, (size_t)cap * h->d.D * 4))) return rc;
+  if (xhat_out && (rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, (size_t)cap * h->user.D * 4))) return rc;
   for (int64_t i0 = 0; i0 < n; i0 += pass) {
     const int64_t nb = n - i0 < pass ? n - i0 : pass;
     const char* xp = reinterpret_cast<const char*>(x) + i0 * stride;
@@ -1283,7 +1423,7 @@ extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int
     HIP_TRY(hipMemcpy(reinterpret_cast<char*>(codes_out) + (size_t)i0 * crow, h->stage_codes, (size_t)nb * crow,
                       hipMemcpyDeviceToHost));
     if (xhat_out)
-      HIP_TRY(hipMemcpy(xhat_out + (size_t)i0 * h->d.D, h->stage_out, (size_t)nb * h->d.D * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(xhat_out + (size_t)i0 * h->user.D, h->stage_out, (size_t)nb * h->user.D * 4, hipMemcpyDeviceToHost));
   }
   return h->split16 ? check_decode_range(h) : QINCO_OK;   // (the split form's overflow flag; the copies above have synchronised)
 }
@@ -1316,7 +1456,7 @@ extern "C" int qinco_decode_host(qinco_handle h, const void* codes, int code_dty
   if (n == 0) return QINCO_OK;
   HIP_TRY(hipSetDevice(h->device));
   const size_t crow = (size_t)h->d.M * code_size(code_dtype);
-  const size_t orow = (size_t)h->d.D * 4;
+  const size_t orow = (size_t)h->user.D * 4;
   const int64_t pass = kDecodeChunk;
   const int64_t cap = n < pass ? n : pass;
   if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, (size_t)cap * crow))) return rc;
@@ -1328,7 +1468,7 @@ extern "C" int qinco_decode_host(qinco_handle h, const void* codes, int code_dty
     HIP_TRY(hipMemcpy(h->stage_codes, reinterpret_cast<const char*>(codes) + (size_t)i0 * crow, (size_t)nb * crow,
                       hipMemcpyHostToDevice));
     if ((rc = qinco_decode(h, h->stage_codes, code_dtype, nb, h->stage_out, flags, nullptr))) return rc;
-    HIP_TRY(hipMemcpy(out + (size_t)i0 * h->d.D, h->stage_out, (size_t)nb * orow, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out + (size_t)i0 * h->user.D, h->stage_out, (size_t)nb * orow, hipMemcpyDeviceToHost));
   }
   return check_decode_range(h);
 }
@@ -1361,7 +1501,7 @@ extern "C" int qinco_profile_read(qinco_handle h, double* mlp_ms, int64_t* mlp_l
 
 extern "C" double qinco_flops_per_vector_encode(qinco_handle h) {
   if (!h) return 0.0;
-  const qinco_desc& d = h->d;
+  const qinco_desc& d = h->user;
   const double rm = mlp_flops_per_row(h);
   double total = 2.0 * d.D * (d.ivf_K > 0 ? d.ivf_K : d.K);  // step 0 table
   int F = (d.M == 1 || d.ivf_K > 0) ? 1 : (h->B < d.K ? h->B : d.K);
@@ -1380,8 +1520,8 @@ extern "C" int qinco_describe(qinco_handle h, char* buf, int32_t cap) {
   if (!h) return fail(QINCO_ERR_INVALID, "qinco_describe: null handle");
   char tmp[512];
   const MlpInstance* i = h->inst;
-  const int n = snprintf(tmp, sizeof(tmp), "mlp=%dx%dx%d P=%d var=%d decode_var=%d form=%s tile=%d table=%s ivf=%s", h->d.D, h->d.De, h->d.Dh,
-                         i ? i->P : 0, i ? i->var : -1, h->dec_inst ? h->dec_inst->var : -1, h->split16 ? "split-fp16" : "fp32",
+  const int n = snprintf(tmp, sizeof(tmp), "model=%dx%dx%d mlp=%dx%dx%d P=%d var=%d decode_var=%d form=%s tile=%d table=%s ivf=%s", h->user.D,
+                         h->user.De, h->user.Dh, h->d.D, h->d.De, h->d.Dh, i ? i->P : 0, i ? i->var : -1, h->dec_inst ? h->dec_inst->var : -1, h->split16 ? "split-fp16" : "fp32",
                          (i && (i->var & 128)) ? 16 : 32, (mfma_table_ok(h->d) && !h->table_valu) ? "mfma" : "valu",
                          h->d.ivf_K == 0 ? "none" : (h->ivf_f16 ? "fp16-filter+fp32" : "fp32"));
   if (buf && cap > 0) {

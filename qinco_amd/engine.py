@@ -71,6 +71,9 @@ class QincoEngine:
             return (_lib.FP * n)()
 
         M, L, K, D, De, Dh = cfg.M_total, cfg.L, cfg.K, cfg.D, cfg.De, cfg.dh
+        if M > 1 and not self.split_f16 and not self.lib.qinco_shape_supported(D, De, Dh):
+            from .build import ensure_instance      # a geometry shapes.def does not list: one kernel instance built on demand
+            ensure_instance(D, De, Dh)
         w = _lib.QincoWeights()
         w.data_mean = ptr("data_mean", (D,))
         std = float(np.asarray(sd["data_std"]).reshape(-1)[0]) if "data_std" in sd else 0.0

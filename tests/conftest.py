@@ -77,11 +77,12 @@ def assert_only_near_ties(oracle, x, got, want, near_tie, label=""):
     xb = np.asarray(x)[bad].astype(np.float32)
     mg = selection_margins(oracle, xb)
     for r, i in enumerate(bad):
+        # (column 0 may differ too: with beams the surviving row can descend from another step-0 candidate -- the flip itself
+        # still happened at some later selection; for an IVF model it can be the coarse arg-min, which the replay covers)
         first = int(np.nonzero(got[i] != want[i])[0][0])
-        assert first > 0 or oracle.ivf, f"{label}: row {i} differs at step 0"
         m = float(mg[r, max(first - 1, 0):].min())
         print(f"{label}: row {i} differs from step {first}; oracle margin there {m:.3e}")
-        assert first == 0 or m < near_tie, f"{label}: row {i} differs although the oracle margin is {m:.3e}"
+        assert (first == 0 and oracle.ivf) or m < near_tie, f"{label}: row {i} differs although the oracle margin is {m:.3e}"
     replay, _ = oracle.encode((xb - oracle.data_mean) / oracle.data_std, prefer=got[bad], tie=near_tie)
     same = (replay.T == got[bad]).all(axis=1)
     assert same.all(), f"{label}: rows {bad[~same].tolist()} are not reachable by the oracle under a {near_tie:g} perturbation"

@@ -64,7 +64,8 @@ def test_shape_table(lib):
     assert lib.qinco_shape_supported(128, 384, 384) == 1      # C2 / C3
     assert lib.qinco_shape_supported(128, 128, 256) == 1      # C1
     assert lib.qinco_shape_supported(768, 384, 384) == 1      # C4
-    assert lib.qinco_shape_supported(100, 384, 384) == 0
+    assert lib.qinco_shape_supported(100, 384, 384) == 1      # zero-padded to the compiled-in (128, 384, 384)
+    assert lib.qinco_shape_supported(128, 416, 384) == 0      # a shape nobody compiled (until ensure_instance builds it)
     assert lib.qinco_version().startswith(b"qinco_hip")
 
 
@@ -122,3 +123,30 @@ def test_product_never_imports_oracle():
     for p in (ROOT / "qinco_amd").rglob("*.py"):
         txt = p.read_text()
         assert "oracle" not in txt.replace("oracle-", ""), p
+
+
+def test_kernel_instance_built_on_demand_and_registered(lib):
+    """A geometry shapes.def does not list: qinco_padded_shape gives the 32-feature-block shape, ensure_instance compiles ONE
+    translation unit of csrc/mlp_inst.hip into a module of its own (hipcc cross-compiles gfx950 without a GPU; cached under
+    qinco_amd/_instances/), qinco_load_instance registers it, and qinco_shape_supported then says yes.  (GPU parity of such
+    models: tests/test_hip_parity.py::test_arbitrary_geometry_*.)"""
+    from qinco_amd.build import ensure_instance, instance_plan
+    out3 = (C.c_int32 * 3)()
+    assert lib.qinco_padded_shape(100, 256, 500, out3) == 0 and list(out3) == [128, 256, 512]
+    assert lib.qinco_padded_shape(100, 128, 256, out3) == 0 and list(out3) == [128, 160, 256]     # projections must survive
+    assert lib.qinco_padded_shape(100, 100, 256, out3) == 0 and list(out3) == [128, 128, 256]     # QINCo1: De == D stays
+    assert lib.qinco_shape_supported(100, 100, 256) == 1                                          # = the compiled-in C1 shape
+    assert instance_plan(128, 256, 512) == (48, 196) and instance_plan(128, 128, 224) == (48, 380)
+    assert instance_plan(224, 224, 320) == (48, 124)
+    with pytest.raises(NotImplementedError):
+        instance_plan(128, 1024, 256)
+    assert lib.qinco_load_instance(b"/nonexistent/module.so") == -1
+    so = ensure_instance(100, 256, 500)
+    if so is None:
+        assert lib.qinco_shape_supported(100, 256, 500) == 1      # already loaded earlier in this process
+    else:
+        assert so.exists() and lib.qinco_shape_supported(100, 256, 500) == 1
+        mod = C.CDLL(str(so))
+        v, fns = (C.c_int32 * 6)(), (C.c_void_p * 2)()
+        assert mod.qinco_instance_info(v, fns) > 0 and list(v)[:5] == [128, 256, 512, 48, 196] and fns[0] and fns[1]
+        assert ensure_instance(100, 256, 500) is None             # second call: nothing to do

@@ -93,14 +93,62 @@ def test_bench_self_launches_ranks_from_a_bare_python():
     rec = _bench("--gpus", "2", "--backend", backend, "--workload", "C1", "--batch", "512", "--steps", "2", "--warmup", "1")
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     mg = rec["multi_gpu"]
+    assert mg["control_plane"] == "gloo" and mg["gather_ok_on_all_ranks"] and mg["per_rank_vectors"] == [1024, 1024]
     assert len(mg["per_rank_encode_vectors_per_s"]) == 2 and all(v > 0 for v in mg["per_rank_encode_vectors_per_s"])
     assert len(mg["per_rank_gather_s"]) == 2 and mg["gather_bytes_per_rank"] == 2 * 512 * 8
     assert abs(rec["value"] - 2 * 2 * 512 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 1e-6
 
 
+def test_bench_strong_scaling_splits_one_database():
+    """--scaling strong: ONE database (here 3 x 512 + 100 rows, so the last shard is longer) split over the ranks like
+    encode_database does (search_tasks.py:103-104); `value` = database size / max-over-ranks time."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 3 else "gloo"
+    rec = _bench("--gpus", "3", "--backend", backend, "--workload", "C1", "--batch", "512", "--steps", "3", "--warmup", "1",
+                 "--scaling", "strong", "--db", "1636")
+    assert rec["n_gpus"] == 3 and rec["scaling"] == "strong" and rec["config"]["distinct_vectors_encoded"] == 1636
+    mg = rec["multi_gpu"]
+    assert mg["per_rank_vectors"] == [545, 545, 546] and mg["gather_ok_on_all_ranks"]
+    assert mg["gather_bytes_per_rank"] == 546 * 8
+    assert abs(rec["value"] - 1636 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-6
+
+
+def test_bench_fails_soft_when_rccl_is_unavailable():
+    """--backend nccl with more ranks than GPUs is refused up front; but an RCCL that fails at run time must not lose the
+    run: the ranks write part files and the line says so.  Simulated by pointing the payload path at a backend that cannot
+    gather (QINCO_BENCH_FORCE_GATHER_ERROR, a test hook read by bench.py only)."""
+    import os
+    os.environ["QINCO_BENCH_FORCE_GATHER_ERROR"] = "1"
+    try:
+        rec = _bench("--gpus", "2", "--backend", "gloo", "--workload", "C1", "--batch", "256", "--steps", "1", "--warmup", "0")
+    finally:
+        del os.environ["QINCO_BENCH_FORCE_GATHER_ERROR"]
+    mg = rec["multi_gpu"]
+    assert rec["value"] > 0 and mg["gather"].startswith("failed:") and "part files" in mg["gather"]
+    assert not mg["gather_ok_on_all_ranks"] and all(v > 0 for v in mg["per_rank_encode_vectors_per_s"])
+
+
+def test_bench_driver_line_carries_the_metric_grid():
+    """The default legs of the driver's N = 1 line (BASELINE.json metric: beam in {1, 8} over its configs): c1 with the
+    oracle code-identity count and its CPU sample, c3, c4, and the bvecs -> encode_database leg (here on a small file)."""
+    rec = _bench("--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--bvecs-vectors", "40000")
+    c1 = rec["c1"]
+    assert "error" not in c1, c1
+    n_same, n_all = (int(v) for v in c1["greedy_rows_equal_to_oracle"].split("/"))
+    assert n_all == 256 and n_same >= 254 and c1["cpu_baseline"]["value"] > 0 and c1["gpu_over_cpu"] > 10
+    assert 0.5 < c1["roofline"]["frac_executed"] <= 1.0
+    for k, M, D in (("c3", 16, 128), ("c4", 8, 768)):
+        assert "error" not in rec[k], rec[k]
+        assert rec[k]["M"] == M and rec[k]["D"] == D and rec[k]["value"] > 0 and 0.5 < rec[k]["roofline"]["frac_executed"] <= 1.0
+    db = rec["encode_db_bvecs"]
+    assert "error" not in db, db
+    assert db["vectors"] == 40000 and db["codes_equal_to_resident_path"] and db["value"] > 0 and db["resident_value"] > 0
+    assert "kernel_instances" in rec["config"]
+
+
 def test_bench_line_schema_single_gpu():
     """A short single-GPU run carries every field of the contract line plus roofline / decode / mse / batch_1024."""
-    rec = _bench("--workload", "C1", "--batch", "2048", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    rec = _bench("--workload", "C1", "--batch", "2048", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-legs")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "decode", "mse", "batch_1024"):
         assert k in rec, k

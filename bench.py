@@ -294,6 +294,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
 
+    # stdout carries exactly ONE line (rank 0's JSON): native libraries print there too (gloo's "[Gloo] Rank 0 is connected
+    # to 7 peer ranks" comes from C++ std::cout), so file descriptor 1 points at stderr until that line is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -483,7 +489,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     if world > 1:
         dist.barrier()

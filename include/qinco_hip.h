@@ -98,8 +98,28 @@ enum {
   QINCO_CREATE_IVF_FP32 = 2,
   QINCO_CREATE_TABLE_VALU = 4,
   QINCO_CREATE_DECODE_FOLDED = 8,
-  QINCO_CREATE_TABLE_NO_COOP = 16
+  QINCO_CREATE_TABLE_NO_COOP = 16,
+  QINCO_CREATE_SPLIT_NO_CALIBRATION = 32   /* skip the create-time comparison with the fp32 instance (below) */
 };
+
+/* The split form checks itself.  (1) At create, unless QINCO_CREATE_SPLIT_NO_CALIBRATION: the model is also built as an fp32
+ * twin, 512 vectors drawn around its own codebooks are encoded by both, and a split form outside the fp32 path's error class
+ * on THIS model (more than 5 % of the code rows differ, reconstructions differ by more than 1e-4 relative, or anything
+ * overflows) makes qinco_create_ex fail with QINCO_ERR_RANGE.  (2) At run time: overflow raises the sticky flag
+ * (qinco_check); underflow is silent by nature, so every 64th workgroup counts how many of the activations' fp16 lo parts
+ * are subnormal (have lost bits).  qinco_split_stats reports both; lo_subnormal / lo_sampled is a few per cent on a healthy
+ * model (values that are themselves close to zero) and approaches 1 when the activations sit far below the design range. */
+typedef struct {
+  int32_t split_form;            /* 1 if the handle runs the split-fp16 kernels */
+  int32_t calibrated;            /* 1 if the create-time calibration ran */
+  int32_t calib_vectors;
+  int32_t calib_rows_differing;  /* code rows that differ between the split and the fp32 instance */
+  float calib_max_rel_err;       /* max |xhat_split - xhat_fp32| / max |xhat_fp32| over the rows with equal codes */
+  int32_t overflowed;            /* 1 if an overflow was ever reported through qinco_check / the host entry points */
+  int64_t lo_sampled;            /* since create: non-zero activation elements inspected */
+  int64_t lo_subnormal;          /* ... of which the fp16 lo part is subnormal */
+} qinco_split_report;
+QINCO_API int qinco_split_stats(qinco_handle h, qinco_split_report* out);
 QINCO_API int qinco_create_ex(const qinco_desc* desc, const qinco_weights* weights, int32_t create_flags, qinco_handle* out);
 
 /* ... and with the remaining diagnostic knobs.  struct_bytes = sizeof(qinco_options) (lets the struct grow); mlp_P / mlp_var

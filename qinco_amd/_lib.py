@@ -12,10 +12,11 @@ X_F32, X_U8 = 0, 1
 CODE_I64, CODE_I32, CODE_U8 = 0, 1, 2
 FLAG_NORMALISED = 1
 CREATE_SPLIT_F16, CREATE_IVF_FP32, CREATE_TABLE_VALU, CREATE_DECODE_FOLDED, CREATE_TABLE_NO_COOP = 1, 2, 4, 8, 16
+CREATE_SPLIT_NO_CALIBRATION = 32
 
 # every symbol include/qinco_hip.h declares (tests check the library exports all of them)
 API_SYMBOLS = [
-    "qinco_create", "qinco_create_ex", "qinco_create_opt", "qinco_describe", "qinco_padded_shape", "qinco_load_instance", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
+    "qinco_create", "qinco_create_ex", "qinco_create_opt", "qinco_describe", "qinco_padded_shape", "qinco_load_instance", "qinco_split_stats", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
     "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
     "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
@@ -32,6 +33,12 @@ class QincoDesc(C.Structure):
 class QincoOptions(C.Structure):
     _fields_ = [("struct_bytes", C.c_int32), ("create_flags", C.c_int32), ("mlp_P", C.c_int32), ("mlp_var", C.c_int32),
                 ("table_coop_max", C.c_int64)]
+
+
+class QincoSplitReport(C.Structure):
+    _fields_ = [("split_form", C.c_int32), ("calibrated", C.c_int32), ("calib_vectors", C.c_int32),
+                ("calib_rows_differing", C.c_int32), ("calib_max_rel_err", C.c_float), ("overflowed", C.c_int32),
+                ("lo_sampled", C.c_int64), ("lo_subnormal", C.c_int64)]
 
 
 FP = C.POINTER(C.c_float)
@@ -98,6 +105,8 @@ def load() -> C.CDLL:
     lib.qinco_padded_shape.restype = C.c_int
     lib.qinco_load_instance.argtypes = [C.c_char_p]
     lib.qinco_load_instance.restype = C.c_int
+    lib.qinco_split_stats.argtypes = [vp, C.POINTER(QincoSplitReport)]
+    lib.qinco_split_stats.restype = C.c_int
     lib.qinco_describe.argtypes = [vp, C.c_char_p, C.c_int32]
     lib.qinco_describe.restype = C.c_int
     lib.qinco_destroy.argtypes = [vp]

@@ -64,6 +64,7 @@ struct MlpArgs {
   const float* qproj;     // FOLD2: (R/A, Dh) Q_g = W_up[0] U_g
   int* err;               // split-fp16 form: sticky flag, set to 2 when a candidate distance is not finite (fp16 overflow)
   const float* smul;      // split-fp16 form (mlp_split_kernel.hpp): [2^c, 2^-c, then per FFN block l: m_up[l], m_down[l]]
+  unsigned long long* stats;  // split-fp16 form: [elements sampled, elements whose fp16 lo part is subnormal] (every 64th workgroup)
 #ifdef QINCO_TIMELINE     // experiment builds only (scripts/exp_timeline.py): per-wave cycle stamps of the kernel's phases
   unsigned long long* timeline;   // (tiles, 8)
 #endif

@@ -402,6 +402,31 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
   }
 
   stamp(3);   // FFN blocks done
+  // Underflow statistic (qinco_split_stats): how many of the activations' fp16 lo parts are subnormal, i.e. have lost bits.
+  // fp16 overflow raises the error flag; underflow is silent by nature, so every 64th workgroup counts it on the final z'
+  // (the register-resident blocks) -- a model whose activations sit far below the scalings' design range shows up here.
+  if (a.stats && (blockIdx.x & 63) == 0) {
+    unsigned nsub = 0, nall = 0;
+    static_for<NZV>([&]<int ob>() QINCO_LAMBDA {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float v = z[ob][i];
+        const _Float16 hi = (_Float16)v;
+        const float lo = (float)(_Float16)(v - (float)hi);
+        nall += (v != 0.f);
+        nsub += (lo != 0.f && __builtin_fabsf(lo) < 6.103515625e-05f);
+      }
+    });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      nsub += __shfl_xor(nsub, o);
+      nall += __shfl_xor(nall, o);
+    }
+    if (lane == 0) {
+      atomicAdd(a.stats, (unsigned long long)nall);
+      atomicAdd(a.stats + 1, (unsigned long long)nsub);
+    }
+  }
   // ---- tail: out_proj + epilogue: cand = (out + coeff*c) + xhat ; dist = |x|^2 + |cand|^2 - 2 x.cand  (mlp_kernel.hpp E) ----
   const long n = g / a.F;
   const float* xptr = a.x ? a.x + n * D + half * 4 : nullptr;

@@ -120,6 +120,9 @@ struct qinco_handle_s {
   std::vector<f32x4*> dec_wstream;
   int* kvals = nullptr;
   int* err_flag = nullptr;
+  unsigned long long* split_stats = nullptr;   // split form: [activations sampled, fp16 lo parts subnormal] (mlp_split_kernel.hpp)
+  qinco_split_report calib{};                  // split form: result of the create-time calibration against the fp32 instance
+  bool ever_overflowed = false;
   // IVF step 0
   int K0 = 0;                       // rows of codebook[0] (ivf_K or K)
   f32x4* ivf_stream = nullptr;      // centroids packed as MFMA A-operand fragments
@@ -708,12 +711,13 @@ struct PaddedWeights {
 // Diagnostic knobs of a handle (qinco_options in the ABI).  Experiment builds (-DQINCO_EXPERIMENT, scripts/) also read them from
 // the environment so that an unmodified caller can be A/B-ed; the shipping library has no environment switches.
 struct CreateOpts {
+  bool calibrate = true;   // split form: compare with an fp32 twin on a calibration batch at create (never for the twin itself)
   int flags = 0;
   int mlp_P = -1, mlp_var = -1;
   long table_coop_max = -1;
 };
 static const int kCreateFlagMask = QINCO_CREATE_SPLIT_F16 | QINCO_CREATE_IVF_FP32 | QINCO_CREATE_TABLE_VALU | QINCO_CREATE_DECODE_FOLDED |
-                                   QINCO_CREATE_TABLE_NO_COOP;
+                                   QINCO_CREATE_TABLE_NO_COOP | QINCO_CREATE_SPLIT_NO_CALIBRATION;
 
 static void env_opts(CreateOpts& o) {
 #ifdef QINCO_EXPERIMENT
@@ -760,8 +764,11 @@ extern "C" int qinco_create_opt(const qinco_desc* desc, const qinco_weights* w, 
   return create_impl(desc, w, o, out);
 }
 
+static int calibrate_split(qinco_handle_s* h, const qinco_desc* desc, const qinco_weights* w, const CreateOpts& opt);
+
 static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpts opt, qinco_handle* out) {
   const int create_flags = opt.flags;
+  const qinco_weights* const w_user = w;   // (w is re-pointed at padded copies below; the calibration twin starts from the user's)
   if (!desc || !w || !out) return fail(QINCO_ERR_INVALID, "qinco_create: null argument");
   // A model without FFN blocks (L = 0) runs as L = 1 with an all-zero block: z + W_down relu(W_up z) = z + 0 exactly, and every
   // kernel form (FOLD2 and the split form peel block 0, the 16-row tile form) then serves it without an instance of its own.
@@ -884,6 +891,10 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
     return bail(fail(QINCO_ERR_HIP, "hipMemcpy(kvals) failed"));
   if ((rc = dev_alloc(h, &h->err_flag, 1))) return bail(rc);
   if (hipMemset(h->err_flag, 0, sizeof(int)) != hipSuccess) return bail(fail(QINCO_ERR_HIP, "hipMemset failed"));
+  if (h->split16) {
+    if ((rc = dev_alloc(h, &h->split_stats, 2))) return bail(rc);
+    if (hipMemset(h->split_stats, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(QINCO_ERR_HIP, "hipMemset failed"));
+  }
 
   for (int m = 0; m < d.M; ++m) {
     if (!w->codebook[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: codebook[%d] is null", m));
@@ -992,7 +1003,98 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
     }
   }
   if ((rc = ensure_scratch(h))) return bail(rc);
+  if (h->split16 && opt.calibrate && !(create_flags & QINCO_CREATE_SPLIT_NO_CALIBRATION) && d.M > 1) {
+    if ((rc = calibrate_split(h, desc, w_user, opt))) return bail(rc);
+  }
   *out = h;
+  return QINCO_OK;
+}
+
+// Create-time calibration of the split-fp16 form: the same model as an fp32 twin, a batch of vectors drawn around the model's
+// own codebooks (sum of one random codeword per step + noise, in the normalised space), both encoded; recorded: code rows that
+// differ, the largest relative difference of the reconstructions on rows with equal codes, non-finite outputs.  A split form
+// that is not in the fp32 path's error class on this model (static power-of-two scalings chosen from the weights, fp16's
+// five exponent bits) is REFUSED here, at create, with QINCO_ERR_RANGE -- not discovered later in somebody's recall numbers.
+static int calibrate_split(qinco_handle_s* h, const qinco_desc* desc, const qinco_weights* w, const CreateOpts& opt) {
+  const int n = 512, D = desc->D, M = desc->M;
+  CreateOpts o2 = opt;
+  o2.flags &= ~QINCO_CREATE_SPLIT_F16;
+  o2.mlp_P = o2.mlp_var = -1;
+  o2.calibrate = false;
+  qinco_desc d2 = *desc;
+  d2.max_batch = n;
+  qinco_handle twin = nullptr;
+  int rc = create_impl(&d2, w, o2, &twin);
+  if (rc) return rc;
+  struct Lcg {
+    unsigned long long s;
+    unsigned next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(s >> 33); }
+    float gauss() {   // sum of 12 uniforms - 6
+      float a = 0.f;
+      for (int i = 0; i < 12; ++i) a += (float)(next() & 0xffffff) / 16777216.f;
+      return a - 6.f;
+    }
+  } rng{0x51ED2701ull};
+  std::vector<float> x((size_t)n * D), xs((size_t)n * D), xf((size_t)n * D);
+  double energy = 0.0;
+  for (int i = 0; i < n; ++i) {
+    float* xi = &x[(size_t)i * D];
+    for (int m = 0; m < M; ++m) {
+      const long rows = (m == 0 && desc->ivf_K > 0) ? desc->ivf_K : desc->K;
+      const float* c = w->codebook[m] + (size_t)(rng.next() % rows) * D;
+      for (int j = 0; j < D; ++j) xi[j] += c[j];
+    }
+    for (int j = 0; j < D; ++j) energy += (double)xi[j] * xi[j];
+  }
+  const float noise = 0.1f * (float)std::sqrt(energy / ((double)n * D) + 1e-30);
+  for (float& v : x) v += noise * rng.gauss();
+  std::vector<int> cs((size_t)n * M), cf((size_t)n * M);
+  rc = qinco_encode_host(h, x.data(), QINCO_X_F32, 0, n, cs.data(), QINCO_CODE_I32, xs.data(), QINCO_FLAG_NORMALISED);
+  const bool range = rc == QINCO_ERR_RANGE;
+  if (rc && !range) { qinco_destroy(twin); return rc; }
+  rc = qinco_encode_host(twin, x.data(), QINCO_X_F32, 0, n, cf.data(), QINCO_CODE_I32, xf.data(), QINCO_FLAG_NORMALISED);
+  qinco_destroy(twin);
+  if (rc) return rc;
+  qinco_split_report& r = h->calib;
+  r.calibrated = 1;
+  r.calib_vectors = n;
+  r.calib_rows_differing = 0;
+  double scale = 0.0, worst = 0.0;
+  for (float v : xf) scale = std::fmax(scale, std::fabs((double)v));
+  bool finite = !range;
+  for (int i = 0; i < n; ++i) {
+    const bool same = std::memcmp(&cs[(size_t)i * M], &cf[(size_t)i * M], (size_t)M * sizeof(int)) == 0;
+    if (!same) { r.calib_rows_differing++; continue; }
+    for (int j = 0; j < D; ++j) {
+      const double e = std::fabs((double)xs[(size_t)i * D + j] - (double)xf[(size_t)i * D + j]);
+      if (!(e == e) || !std::isfinite(xs[(size_t)i * D + j])) finite = false;
+      else worst = std::fmax(worst, e);
+    }
+  }
+  r.calib_max_rel_err = scale > 0.0 ? (float)(worst / scale) : 0.f;
+  (void)hipMemset(h->split_stats, 0, 2 * sizeof(unsigned long long));   // the counters report production work only
+  if (!finite)
+    return fail(QINCO_ERR_RANGE, "qinco_create: the split-fp16 form overflows on this model (calibration batch of %d vectors around its "
+                "codebooks): use the fp32 path", n);
+  if (r.calib_max_rel_err > 1e-4f || r.calib_rows_differing > n / 20)
+    return fail(QINCO_ERR_RANGE, "qinco_create: the split-fp16 form is not in the fp32 path's error class on this model (calibration: %d of "
+                "%d code rows differ, reconstructions differ by %.2e relative): use the fp32 path", r.calib_rows_differing, n,
+                (double)r.calib_max_rel_err);
+  return 0;
+}
+
+extern "C" int qinco_split_stats(qinco_handle h, qinco_split_report* out) {
+  if (!h || !out) return fail(QINCO_ERR_INVALID, "qinco_split_stats: null argument");
+  *out = h->calib;
+  out->split_form = h->split16 ? 1 : 0;
+  if (!h->split16) return QINCO_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long v[2] = {0, 0};
+  HIP_TRY(hipMemcpy(v, h->split_stats, sizeof(v), hipMemcpyDeviceToHost));
+  out->lo_sampled = (int64_t)v[0];
+  out->lo_subnormal = (int64_t)v[1];
+  out->overflowed = h->ever_overflowed ? 1 : 0;
   return QINCO_OK;
 }
 
@@ -1070,6 +1172,7 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
   }
   a.smul = h->split16 ? h->smul[m] : nullptr;
   a.err = h->split16 ? h->err_flag : nullptr;
+  a.stats = h->split16 ? h->split_stats : nullptr;
 #ifdef QINCO_TIMELINE
   {
     const size_t tiles = (size_t)((a.R + 31) / 32 + 4);
@@ -1435,6 +1538,7 @@ static int check_decode_range(qinco_handle_s* h) {
   HIP_TRY(hipMemcpy(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost));
   if (flag) {
     HIP_TRY(hipMemset(h->err_flag, 0, sizeof(int)));
+    if (flag == 2) h->ever_overflowed = true;
     if (flag == 2)
       return fail(QINCO_ERR_RANGE, "split-fp16 form: an activation of the codeword MLP left the fp16 range (or the input is not finite); "
                                    "create the handle without QINCO_CREATE_SPLIT_F16 for this model / data");

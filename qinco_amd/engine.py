@@ -29,14 +29,16 @@ class QincoEngine:
         """split_f16: opt-in split-fp16 evaluation of the FFN blocks (include/qinco_hip.h, QINCO_CREATE_SPLIT_F16): several
         times the fp32-MFMA throughput, fp32-class accuracy but not the fp32 path's bits.
         diagnostics: qinco_options knobs for A/B runs and the race-detector tests -- ivf_fp32, table_valu, decode_folded,
-        table_no_coop (bools), mlp_variant=(P, VAR) (a non-production kernel instance of csrc/shapes.def), table_coop_max."""
+        table_no_coop, split_no_calibration (bools), mlp_variant=(P, VAR) (a non-production kernel instance of
+        csrc/shapes.def), table_coop_max."""
         self.lib = _lib.load()
         self.cfg = cfg
         self.split_f16 = bool(split_f16)
         diag = dict(diagnostics or {})
         flags = _lib.CREATE_SPLIT_F16 if self.split_f16 else 0
         for key, bit in (("ivf_fp32", _lib.CREATE_IVF_FP32), ("table_valu", _lib.CREATE_TABLE_VALU),
-                         ("decode_folded", _lib.CREATE_DECODE_FOLDED), ("table_no_coop", _lib.CREATE_TABLE_NO_COOP)):
+                         ("decode_folded", _lib.CREATE_DECODE_FOLDED), ("table_no_coop", _lib.CREATE_TABLE_NO_COOP),
+                         ("split_no_calibration", _lib.CREATE_SPLIT_NO_CALIBRATION)):
             if diag.pop(key, False):
                 flags |= bit
         P, var = diag.pop("mlp_variant", None) or (-1, -1)
@@ -241,6 +243,15 @@ class QincoEngine:
         c, f = C.c_int64(), C.c_int32()
         _lib.check(self.lib.qinco_ivf_last_stats(self._h, C.byref(c), C.byref(f)))
         return {"candidates": c.value, "fell_back": bool(f.value)}
+
+    def split_stats(self) -> dict:
+        """qinco_split_stats: the split-fp16 form's create-time calibration against the fp32 instance and its run-time
+        underflow / overflow statistics (include/qinco_hip.h)."""
+        r = _lib.QincoSplitReport()
+        _lib.check(self.lib.qinco_split_stats(self._h, C.byref(r)))
+        d = {k: getattr(r, k) for k, _ in r._fields_}
+        d["lo_subnormal_frac"] = (r.lo_subnormal / r.lo_sampled) if r.lo_sampled else None
+        return d
 
     def describe(self) -> str:
         """qinco_describe: which kernel instances / arithmetic form serve this handle."""

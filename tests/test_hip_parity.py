@@ -133,6 +133,40 @@ def test_split_f16_encode_matches_oracle_fresh_inputs(split_engines, name, n):
     assert rel_err(eng.decode(got)[ok], oracle(want.T, step="decode")[ok]) < REL_TOL
 
 
+def test_split_f16_checks_itself_at_create_and_at_run_time(split_engines):
+    """qinco_split_stats: the create-time calibration against an fp32 twin (512 vectors around the model's own codebooks) and
+    the run-time underflow counter.  A healthy model: calibrated, (nearly) no differing rows, reconstructions within 1e-5, a
+    small subnormal fraction.  A model whose activations sit 2^-20 below the scalings' design range computes garbage-free but
+    bit-poor products: the underflow fraction says so, and the calibration REFUSES the handle at create."""
+    from qinco_amd import QincoEngine, synth_vectors
+    for name in ("trained_qinco2S", "C2_qinco2L_8x8_b8", "tiny_proj_dh128"):
+        cfg, sd, eng = split_engines(name)
+        st = eng.split_stats()
+        assert st["split_form"] == 1 and st["calibrated"] == 1 and st["calib_vectors"] == 512, st
+        assert st["calib_rows_differing"] <= 5 and st["calib_max_rel_err"] < 1e-5 and st["overflowed"] == 0, st
+        eng.encode(load_golden(name)["x"])
+        st = eng.split_stats()
+        print(name, st)
+        assert st["lo_sampled"] > 0 and st["lo_subnormal_frac"] < 0.25, st
+    cfg, sd, _ = split_engines("tiny_proj_dh128")
+    tiny = dict(sd)
+    for k in sd:      # every codebook and the concat layer 2^-20 smaller: z ~ 1e-6, far below the range z' = 8 z was designed for
+        if k.endswith("codebook.weight") or "concat.mlp.bias" in k:
+            tiny[k] = sd[k] * np.float32(2.0 ** -20)
+    with pytest.raises(IndexError, match="error class|overflows"):
+        QincoEngine(cfg, tiny, max_batch=256, split_f16=True)
+    e2 = QincoEngine(cfg, tiny, max_batch=256, split_f16=True, diagnostics={"split_no_calibration": True})
+    x = (synth_vectors(cfg, sd, 256, seed=5) - sd["data_mean"]) * np.float32(2.0 ** -20) + sd["data_mean"]
+    e2.encode(x)
+    st = e2.split_stats()
+    print("2^-20 model:", st)
+    assert st["calibrated"] == 0 and st["lo_subnormal_frac"] > 0.5, st
+    e2.close()
+    e3 = QincoEngine(cfg, tiny, max_batch=256)            # the fp32 path takes the same model as it is
+    assert e3.split_stats()["split_form"] == 0
+    e3.close()
+
+
 def test_split_f16_ragged_batches_and_overflow_flag(split_engines):
     """Row counts that are not multiples of the 32-row tile / of max_batch give the codes of the full batch; a model whose
     activations leave the fp16 range is reported (QINCO_ERR_RANGE -> IndexError), not encoded from NaNs."""
@@ -146,9 +180,12 @@ def test_split_f16_ragged_batches_and_overflow_flag(split_engines):
     assert np.array_equal(eng.decode(full[:77]), eng.decode(full)[:77])
     big = dict(sd)
     big["steps.1.concat.mlp.bias"] = sd["steps.1.concat.mlp.bias"] * np.float32(3e5)
-    e2 = QincoEngine(cfg, big, max_batch=256, split_f16=True)
-    with pytest.raises(IndexError, match="fp16 range"):
+    with pytest.raises(IndexError, match="overflows"):      # the create-time calibration refuses such a model ...
+        QincoEngine(cfg, big, max_batch=256, split_f16=True)
+    e2 = QincoEngine(cfg, big, max_batch=256, split_f16=True, diagnostics={"split_no_calibration": True})
+    with pytest.raises(IndexError, match="fp16 range"):     # ... and without it the run-time flag still catches it
         e2.encode(x[:64])
+    assert e2.split_stats()["overflowed"] == 1
     e2.close()
     e3 = QincoEngine(cfg, big, max_batch=256)             # the fp32 path has no such limit
     assert e3.encode(x[:64]).shape == (64, cfg.M)

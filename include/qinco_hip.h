@@ -107,8 +107,11 @@ enum {
  * on THIS model (more than 5 % of the code rows differ, reconstructions differ by more than 1e-4 relative, or anything
  * overflows) makes qinco_create_ex fail with QINCO_ERR_RANGE.  (2) At run time: overflow raises the sticky flag
  * (qinco_check); underflow is silent by nature, so every 64th workgroup counts how many of the activations' fp16 lo parts
- * are subnormal (have lost bits).  qinco_split_stats reports both; lo_subnormal / lo_sampled is a few per cent on a healthy
- * model (values that are themselves close to zero) and approaches 1 when the activations sit far below the design range. */
+ * are subnormal (have lost bits).  qinco_split_stats reports both.  A subnormal lo part costs at most 2^-25 absolute per element, so
+ * lo_subnormal / lo_sampled is a drift indicator, not an error: measured 0.02-0.1 on the synthetic models and 0.32 on a
+ * checkpoint trained by the reference (its later steps quantise small residuals, |z| ~ 0.05: calibration error 2.9e-7, no
+ * code row changed); it approaches 1 when the activations sit orders of magnitude below the design range -- the regime in
+ * which the calibration starts to fail (tests/test_hip_parity.py::test_split_f16_checks_itself_*). */
 typedef struct {
   int32_t split_form;            /* 1 if the handle runs the split-fp16 kernels */
   int32_t calibrated;            /* 1 if the create-time calibration ran */
@@ -192,6 +195,19 @@ QINCO_API int qinco_describe(qinco_handle h, char* buf, int32_t cap);
 QINCO_API int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh);
 QINCO_API int qinco_padded_shape(int32_t D, int32_t De, int32_t Dh, int32_t* out3);
 QINCO_API int qinco_load_instance(const char* path);
+
+/* ---- multi-GPU: the one collective of the path -------------------------------------------------------
+ * Database encoding shards over vectors with no exchange (search_tasks.py:103-104); at the end of the job the ranks' codes go
+ * to one root.  The reference writes per-rank part files instead (search_tasks.py:119-134); the Python host here gathers with
+ * torch.distributed (qinco_amd/encode_db.py); this entry point is the same exchange for a C / C++ host that owns an RCCL
+ * communicator: grouped ncclSend / ncclRecv of the raw code bytes (each peer reaches the root over its own xGMI link).
+ *   codes_local  device (n_local, M) of code_dtype on this rank          counts[world]  rows of every rank (shards are uneven:
+ *   out          device (sum counts, M) on `root` (ignored elsewhere)                   the last one takes the remainder)
+ *   nccl_comm    the host's ncclComm_t (one rank per GPU); world == 1 needs none: a device copy
+ * Enqueued on `stream`, not synchronised.  RCCL is resolved at call time from the libraries already loaded in the process
+ * (the one that made the communicator), else librccl.so.1; QINCO_ERR_UNSUPPORTED when there is none. */
+QINCO_API int qinco_gather_codes(const void* codes_local, int64_t n_local, int32_t M, int code_dtype, void* out,
+                                 const int64_t* counts, int32_t world, int32_t rank, int32_t root, void* nccl_comm, void* stream);
 
 /* ---- look-up decoders downstream of the hot path --------------------------------------------
  * out[n] = sum_j tables[j][ codes[n][a[j]] * mul + (b[j] >= 0 ? codes[n][b[j]] : 0) ]   (fp32, summed in j order)

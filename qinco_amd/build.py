@@ -95,8 +95,9 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     # on v_accvgpr_read / write (csrc/ivf_f16_kernel.hpp).  The fused-MLP instances are separate objects and keep their plan.
     o = OBJ / "qinco_hip.o"
     want(o, [cc, *FLAGS, "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", str(CSRC / "qinco_hip.hip"), "-o", str(o)])
-    o = OBJ / "search_hip.o"
-    want(o, [cc, *FLAGS, "-c", str(CSRC / "search_hip.hip"), "-o", str(o)])
+    for name in ("search_hip", "comm_hip"):
+        o = OBJ / f"{name}.o"
+        want(o, [cc, *FLAGS, "-c", str(CSRC / f"{name}.hip"), "-o", str(o)])
     if tasks:
         if verbose:
             print(f"[qinco_amd.build] compiling {len(tasks)} object(s) for {ARCH}", file=sys.stderr)

@@ -74,6 +74,44 @@ def test_two_ranks_rccl(tmp_path):
     _check_outputs(tmp_path, 2, 1203)
 
 
+def test_native_gather_entry_point_single_rank():
+    """qinco_gather_codes with world = 1 (no communicator): the root's own shard lands in the output; argument errors are
+    status codes.  (Two ranks over RCCL: test_two_ranks_native_rccl_gather, needs two GPUs.)"""
+    import ctypes as C
+    import torch
+    from qinco_amd import _lib
+    from qinco_amd.comm import gather_codes_native
+    codes = torch.arange(37 * 8, dtype=torch.int32, device="cuda").reshape(37, 8) % 256
+    for dt in (torch.uint8, torch.int32, torch.int64):
+        c = codes.to(dt)
+        out = gather_codes_native(c, [37], rank=0)
+        assert out.dtype == dt and torch.equal(out, c)
+    lib = _lib.load()
+    cnt = (C.c_int64 * 2)(37, 5)
+    assert lib.qinco_gather_codes(codes.data_ptr(), 36, 8, _lib.CODE_I32, None, cnt, 2, 0, 0, None, None) == -1     # n_local != counts[rank]
+    assert lib.qinco_gather_codes(codes.data_ptr(), 37, 8, _lib.CODE_I32, codes.data_ptr(), cnt, 2, 0, 0, None, None) == -1   # no communicator
+    assert b"communicator" in lib.qinco_last_error()
+
+
+def test_two_ranks_native_rccl_gather(tmp_path):
+    """The C-ABI route of SURVEY 8(e): one process per GPU, RCCL communicator created through ctypes (no torch.distributed),
+    qinco_gather_codes (grouped ncclSend / ncclRecv of uneven shards) -- gathered codes equal the 1-process codes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    n = 1203
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "rank_worker_native.py"), str(r), "2", str(tmp_path / "uid"),
+                               str(tmp_path), str(n)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    _, want = _single_process_codes(n)
+    assert np.array_equal(np.load(tmp_path / "gathered_native.npy"), want)
+
+
 def _bench(*args):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)

@@ -394,61 +394,7 @@ dist_topk_mfma_coop_kernel(const float* __restrict__ x, const float* __restrict_
     }
   }
   __syncthreads();
-  unsigned long long* surv = surv_all + wave * SGP * SEL_SURV;
-  const long gend = G - g0 < 32 ? G - g0 : 32;
-  const int r_lo = wave * 8, r_hi = r_lo + 8 < gend ? r_lo + 8 : (int)gend;   // this wave's rows of the table
-  if (T > 1 && T <= 64) {
-    for (int r0 = r_lo; r0 < r_hi; r0 += SGP) {
-      int rank[SGP], index[SGP];
-      const unsigned ok = wave_select_smallest_multi<SGP, K / 64>(table + r0 * LDK, LDK, T, surv, lane, rank, index);
-#pragma unroll
-      for (int u = 0; u < SGP; ++u) {
-        const int r = r0 + u;
-        if (r >= r_hi) break;
-        if ((ok >> u) & 1) {
-          if (rank[u] >= 0) ids_out[(g0 + r) * T + rank[u]] = index[u];
-          continue;
-        }
-        float* dg = table + r * LDK;   // massive exact ties: the arg-min rounds
-        for (int t = 0; t < T; ++t) {
-          float bv = __builtin_inff();
-          int bi = 0x7fffffff;
-#pragma unroll
-          for (int k = lane; k < K; k += 64) {
-            const float v = dg[k];
-            const bool take = v < bv;
-            bv = take ? v : bv;
-            bi = take ? k : bi;
-          }
-          wave_argmin(bv, bi);
-          if (bi == 0x7fffffff) bi = 0;
-          if (lane == 0) ids_out[(g0 + r) * T + t] = bi;
-          if ((bi & 63) == lane) dg[bi] = __builtin_inff();
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-    }
-  } else {
-    for (int r = r_lo; r < r_hi; ++r) {   // T == 1 or T > 64: rounds of wave arg-min (see dist_topk_mfma_kernel)
-      float* dg = table + r * LDK;
-      for (int t = 0; t < T; ++t) {
-        float bv = __builtin_inff();
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int k = lane; k < K; k += 64) {
-          const float v = dg[k];
-          const bool take = v < bv;
-          bv = take ? v : bv;
-          bi = take ? k : bi;
-        }
-        wave_argmin(bv, bi);
-        if (bi == 0x7fffffff) bi = 0;
-        if (lane == 0) ids_out[(g0 + r) * T + t] = bi;
-        if ((bi & 63) == lane) dg[bi] = __builtin_inff();
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  }
+  coop_select_rows<K, LDK, SGP>(table, surv_all + wave * SGP * SEL_SURV, lane, wave, g0, G, T, ids_out);
 }
 
 }  // namespace qinco

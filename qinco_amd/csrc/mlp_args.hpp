@@ -78,6 +78,17 @@ struct XprojArgs {
   const f32x4* wq;        // FOLD2: W_up[0] (Dh x De) as fragments in (ob, ib, q) order, or nullptr
   float* qproj;           // FOLD2: (G, Dh)
   const float* smul;      // split-fp16 form (xproj_split_kernel): [2^cx, 1/(2^cx s_u), 2^cu, 1/(2^cu s_q)]; wx = the whole stream
+  // small launches: the step's pre-selection rides in the same kernel (presel_kernel.hpp); cstream == nullptr: plain xproj
+  const float* x;         // (G / F, D) normalised targets
+  int F;                  // beams per vector
+  const f32x4* cstream;   // pre-selection codebook (K = 256) as MFMA fragments (cb, ib, q)
+  const float* cnorm;     // (K) |c_k|^2
+  int T;                  // candidates to keep per group
+  int* ids_out;           // (G, T)
 };
+// 1 if the instance's xproj launcher serves XprojArgs::cstream (the fused small-launch kernel exists for the shape)
+constexpr bool presel_coop_ok(int DE, int DH, int var) {
+  return (DE / 32) % 4 == 0 && (DH / 32) % 4 == 0 && DE <= 384 && (var & 16) && !(var & 128) && !(var & 512);
+}
 
 }  // namespace qinco

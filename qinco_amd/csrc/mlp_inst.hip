@@ -4,6 +4,7 @@
 #include "mlp_kernel.hpp"
 #include "mlp16_kernel.hpp"
 #include "mlp_split_kernel.hpp"
+#include "presel_kernel.hpp"
 #include "mlp_launch.hpp"
 
 #define QINCO_CAT_(a, b, c, d, e, f) a##b##_##c##_##d##_##e##_##f
@@ -76,6 +77,14 @@ hipError_t QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::X
   return hipErrorNotSupported;  // the 16-row form is never folded
 #else
   if (a->G <= 0) return hipSuccess;
+  if (a->cstream) {   // small launch with the step's pre-selection fused in (the host checked presel_coop_ok for this instance)
+    if constexpr (qinco::presel_coop_ok(QDE, QDH, QVAR)) {
+      hipLaunchKernelGGL((qinco::presel_xproj_coop_kernel<QD, QDE, QDH, 8>), dim3((unsigned)((a->G + 31) / 32)), dim3(256), 0, stream, *a);
+      return hipGetLastError();
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
   const unsigned grid = (unsigned)((a->G + 127) / 128);
   hipLaunchKernelGGL((qinco::xproj_kernel<QD, QDE, QDH>), dim3(grid), dim3(256), 0, stream, *a);
   return hipGetLastError();

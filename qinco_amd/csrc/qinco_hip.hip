@@ -130,6 +130,7 @@ struct qinco_handle_s {
   // fp16-filter passes of the IVF assignment (ivf_f16_kernel.hpp)
   bool table_valu = false;          // QINCO_CREATE_TABLE_VALU: VALU pre-selection table kernel (A/B)
   bool table_coop = true;           // small launches: the cooperative table kernel (QINCO_CREATE_TABLE_NO_COOP clears it)
+  bool no_presel_fusion = false;    // QINCO_CREATE_NO_PRESEL_FUSION: pre-selection and xproj as two launches at every size (A/B)
   long table_coop_max = 16384;      // ... up to this many groups
   bool ivf_f16 = false;
   void* ivf_h16 = nullptr;           // centroids as fp16 MFMA fragments
@@ -717,7 +718,7 @@ struct CreateOpts {
   long table_coop_max = -1;
 };
 static const int kCreateFlagMask = QINCO_CREATE_SPLIT_F16 | QINCO_CREATE_IVF_FP32 | QINCO_CREATE_TABLE_VALU | QINCO_CREATE_DECODE_FOLDED |
-                                   QINCO_CREATE_TABLE_NO_COOP | QINCO_CREATE_SPLIT_NO_CALIBRATION;
+                                   QINCO_CREATE_TABLE_NO_COOP | QINCO_CREATE_SPLIT_NO_CALIBRATION | QINCO_CREATE_NO_PRESEL_FUSION;
 
 static void env_opts(CreateOpts& o) {
 #ifdef QINCO_EXPERIMENT
@@ -726,6 +727,7 @@ static void env_opts(CreateOpts& o) {
   if (getenv("QINCO_TABLE_VALU")) o.flags |= QINCO_CREATE_TABLE_VALU;
   if (getenv("QINCO_DECODE_FOLDED")) o.flags |= QINCO_CREATE_DECODE_FOLDED;
   if (getenv("QINCO_TABLE_NO_COOP")) o.flags |= QINCO_CREATE_TABLE_NO_COOP;
+  if (getenv("QINCO_NO_PRESEL_FUSION")) o.flags |= QINCO_CREATE_NO_PRESEL_FUSION;
   if (const char* e = getenv("QINCO_TABLE_COOP_MAX")) o.table_coop_max = atol(e);
   if (const char* e = getenv("QINCO_MLP_VARIANT")) sscanf(e, "%d,%d", &o.mlp_P, &o.mlp_var);
 #else
@@ -842,6 +844,7 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   h->std_ = w->data_std;
   h->table_valu = (create_flags & QINCO_CREATE_TABLE_VALU) != 0;
   h->table_coop = !(create_flags & QINCO_CREATE_TABLE_NO_COOP);
+  h->no_presel_fusion = (create_flags & QINCO_CREATE_NO_PRESEL_FUSION) != 0;
   if (opt.table_coop_max >= 0) h->table_coop_max = opt.table_coop_max;
   const int kRing = fn ? fn->P : 8;
   h->fold = fn && (fn->var & 16);
@@ -1138,7 +1141,22 @@ static unsigned ew_grid(long total) {
 
 // One step's fused MLP over a.R rows.  FOLD: a.uproj names the scratch for U (encode: h->uproj, decode: h->duproj);
 // it is filled here by xproj_kernel for the R/A groups of this launch, and T comes from the step's table.
-static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool decode = false) {
+struct PreselJob {   // the step's pre-selection, when it rides in the xproj launch (small launches, presel_kernel.hpp)
+  const float* x = nullptr;
+  int F = 1, T = 0;
+  const f32x4* cstream = nullptr;
+  const float* cnorm = nullptr;
+  int* ids = nullptr;
+};
+
+// the fused pre-selection + xproj kernel serves this launch: K = 256 MFMA table, a folded fp32 instance whose block counts split
+// over four waves, a launch small enough for the cooperative form
+static bool presel_fused(const qinco_handle_s* h, long G) {
+  return h->inst && h->table_coop && !h->table_valu && !h->split16 && h->fold && G <= h->table_coop_max && h->d.K == 256 &&
+         mfma_table_ok(h->d) && presel_coop_ok(h->d.De, h->d.Dh, h->inst->var) && !h->no_presel_fusion;
+}
+
+static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool decode = false, const PreselJob* pj = nullptr) {
   const bool unfolded = decode && h->dec_inst;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->prof) {   // the bracket covers xproj + mlp: all the work the algorithmic FLOP count stands for
@@ -1167,6 +1185,14 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
       a.ptab = h->ptab[m];
     }
     xa.smul = h->split16 ? h->xsmul[m] : nullptr;
+    if (pj) {
+      xa.x = pj->x;
+      xa.F = pj->F;
+      xa.cstream = pj->cstream;
+      xa.cnorm = pj->cnorm;
+      xa.T = pj->T;
+      xa.ids_out = pj->ids;
+    }
     HIP_TRY(h->inst->xproj(&xa, st));
     a.ttab = h->ttab[m];
   }
@@ -1348,7 +1374,17 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
     const int Ae = A > 0 ? Am : K;
     const long G = (long)n * F;
     const int* cand_ids = nullptr;
-    if (A > 0) {
+    PreselJob pj;
+    const bool fused = A > 0 && presel_fused(h, G);
+    if (fused) {   // small launch: the table + top-A ride in the xproj launch
+      pj.x = h->xn;
+      pj.F = F;
+      pj.T = Am;
+      pj.cstream = h->sub_stream[m];
+      pj.cnorm = h->sub_cnorm[m];
+      pj.ids = h->top_ids;
+      cand_ids = h->top_ids;
+    } else if (A > 0) {
       if ((rc = launch_dist_topk(h, h->xn, h->xhat[cur], F, h->sub_codebook[m], h->sub_stream[m], h->sub_cnorm[m], G, Am, h->top_ids,
                                  st)))
         return rc;
@@ -1368,7 +1404,7 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
     a.dist_out = h->dist;
     a.add_c = d.qinco1_mode ? 0 : 1;
     a.uproj = h->uproj;
-    if ((rc = launch_mlp(h, a, m, st))) return rc;
+    if ((rc = launch_mlp(h, a, m, st, false, fused ? &pj : nullptr))) return rc;
     const int C = F * Ae;
     const int T = Fout_cfg < C ? Fout_cfg : C;
     const size_t lds = (size_t)4 * (((C + T + 3) & ~3) + 2 * SEL_SURV) * sizeof(float);

@@ -354,6 +354,27 @@ def test_arbitrary_geometry_builds_an_instance_on_demand(kw):
     eng.close()
 
 
+@pytest.mark.parametrize("model,D,B", [("qinco2-S", 128, 8), ("qinco2-L", 128, 8), ("qinco2-S", 768, 4), ("qinco2-S", 96, 8),
+                                       ("qinco2-M", 256, 32)])
+def test_fused_preselection_launch_is_bit_identical_to_the_two_kernels(model, D, B):
+    """Small launches (<= 16 384 groups) run the step's pre-selection table + top-A inside the xproj launch
+    (csrc/presel_kernel.hpp); same accumulation chains, same selection code: codes AND reconstructions must equal the
+    two-launch form bit for bit, at several batch sizes around the tile and workgroup boundaries."""
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    from qinco_amd.config import preset
+    cfg = preset(model, D=D, M=3, B=B)
+    sd = synth_state_dict(cfg, 31 + D)
+    x = synth_vectors(cfg, sd, 1500, seed=32)
+    fused = QincoEngine(cfg, sd, max_batch=1024)
+    plain = QincoEngine(cfg, sd, max_batch=1024, diagnostics={"no_presel_fusion": True})
+    for n in (1, 31, 33, 257, 1024, 1500):
+        cf, hf = fused.encode(x[:n], return_xhat=True)
+        cp, hp = plain.encode(x[:n], return_xhat=True)
+        assert np.array_equal(cf, cp) and np.array_equal(hf, hp), n
+    fused.close()
+    plain.close()
+
+
 def test_errors_mirror_reference(engines):
     from qinco_amd import QincoEngine, synth_state_dict
     cfg, sd, eng = engines("tiny_id_qinco1")

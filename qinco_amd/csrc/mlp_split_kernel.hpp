@@ -412,9 +412,10 @@ __global__ void __launch_bounds__(256, 1) mlp_split_kernel(MlpArgs a) {
       for (int i = 0; i < 16; ++i) {
         const float v = z[ob][i];
         const _Float16 hi = (_Float16)v;
-        const float lo = (float)(_Float16)(v - (float)hi);
+        const float rem = v - (float)hi;                       // what the lo part has to carry
+        const float lo = (float)(_Float16)rem;
         nall += (v != 0.f);
-        nsub += (lo != 0.f && __builtin_fabsf(lo) < 6.103515625e-05f);
+        nsub += (rem != 0.f && __builtin_fabsf(lo) < 6.103515625e-05f);   // subnormal, or flushed to zero altogether
       }
     });
 #pragma unroll

@@ -524,14 +524,14 @@ __global__ void __launch_bounds__(256) xproj_kernel(XprojArgs a) {
                                          (__attribute__((address_space(3))) void*)(lds_w + ((C & 1) * CH + f) * 64), 16, 0, 0);
     });
   };
-  // boundary before chunk C of a stream whose output blocks take FPO fragments each: this wave's DMAs of chunk C have
-  // landed -- they are older than the block stores issued while chunk C-1 was consumed (4 per finished block, issued by every
-  // lane, so the count is exact and vmcnt retires in order) --, every wave is done with the other buffer, chunk C+1 is requested
+  // boundary before chunk C: this wave's DMAs of chunk C have landed, every wave is done with the other buffer, chunk C+1 is
+  // requested.  The wait is vmcnt(0): round 2 counted the block stores issued since the DMAs (4 per finished block) and waited
+  // for exactly the DMAs -- correct only as long as hipcc emits exactly one global_store_dwordx4 per source-level store, which
+  // is a property of code generation, not of the source (advisor, round 2); the full wait costs < 2 % of this kernel, which is
+  // itself 1-3 % of a step.
   auto boundary = [&]<int C, int NF, int FPO>(const f32x4* stream) QINCO_LAMBDA {
-    constexpr int lo = C > 0 ? (C - 1) * CH : 0, hi = C * CH;
-    constexpr int nstores = C > 0 ? 4 * ((hi / FPO) - (lo / FPO)) : 0;   // blocks finished inside [lo, hi)
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (nstores & 15) | ((nstores >> 4) << 14));
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr ((C + 1) * CH < NF) dma_chunk.template operator()<C + 1, NF>(stream);

@@ -32,7 +32,7 @@ Also in the line (N = 1, measured after the timed region):
   `c1` -- BASELINE configs[0] / the north_star's literal target (qinco1 8x8, greedy): vectors/s, roofline, the number of
           code rows equal to the oracle's on a 256-vector sample, and the oracle's own rate on that sample (CPU baseline);
   `c3`, `c4` -- BASELINE configs[2] (M = 16) and configs[3] (D = 768) at their bench batch, with roofline;
-  `encode_db_bvecs` -- the actual `task=encode` data path (search_tasks.py:85-137): a uint8 .bvecs file on disk ->
+  `encode_db_bvecs` (C2) and `encode_db_bvecs_qinco2S` -- the actual `task=encode` data path (search_tasks.py:85-137): a uint8 .bvecs file on disk ->
           get_data_memmap -> encode_database(QINCoHIP) -> part file, i.e. host buffers / PCIe included, next to the
           HBM-resident rate of the same model.
 cpu_baseline: the oracle restatement with its codeword MLP on torch CPU ops (oracle/qinco_oracle.py, backend "torch":
@@ -217,7 +217,7 @@ def leg_workload(torch, dev, name, steps, batch, oracle_sample=0):
     return out
 
 
-def leg_encode_db_bvecs(torch, dev, n_db, batch):
+def leg_encode_db_bvecs(torch, dev, n_db, batch, workload="C2"):
     """`task=encode` end to end (search_tasks.py:85-137): BigANN-style uint8 .bvecs on disk -> memmap (strided rows) ->
     encode_database(QINCoHIP) in host batches (qinco_encode_host: H2D of the bytes, uint8 -> fp32 and normalisation on the
     GPU, D2H of the codes) -> `<out>.npz` + part file.  Model: the C2 network with BigANN-magnitude normalisation constants
@@ -226,7 +226,7 @@ def leg_encode_db_bvecs(torch, dev, n_db, batch):
     from qinco_amd.config import BASELINE_CONFIGS
     from qinco_amd.encode_db import EncodedDBIterator, encode_database, get_data_memmap
     from qinco_amd.model import QINCoHIP
-    cfg = BASELINE_CONFIGS["C2"]
+    cfg = BASELINE_CONFIGS[workload]
     sd = apply_regime(cfg, synth_state_dict(cfg, 1236), "bigann", 1236)
     model = QINCoHIP(cfg, sd, max_batch=batch)
     block = regime_vectors(cfg, sd, 65536, "bigann", seed=99)           # uint8 (65536, D); the file repeats it with a roll
@@ -247,6 +247,9 @@ def leg_encode_db_bvecs(torch, dev, n_db, batch):
         t0 = time.perf_counter()
         codes = encode_database(model, db, out_path, K=cfg.K, M=cfg.M, D=cfg.D, batch=4 * batch)
         dt = time.perf_counter() - t0
+        t0 = time.perf_counter()          # the reference's writer on the same codes: one core, at the end of the job
+        np.savez_compressed(os.path.join(tmp, "ref_way.npz"), codes=codes)
+        dt_ref_writer = time.perf_counter() - t0
         it = EncodedDBIterator(out_path, K=cfg.K, M=cfg.M, D=cfg.D)
         part_bytes = os.path.getsize(out_path[:-4] + ".part_0.npz")
         assert it.n_parts == 1 and codes.shape == (n_db, cfg.M)
@@ -262,12 +265,15 @@ def leg_encode_db_bvecs(torch, dev, n_db, batch):
         same = bool(np.array_equal(cres.cpu().numpy().astype(np.int64), codes[:n_res]))
     model.engine.close()
     torch.cuda.empty_cache()
-    return {"value": n_db / dt, "unit": "vectors/s", "vectors": n_db, "seconds": dt, "host_batch": 4 * batch,
+    return {"workload": workload, "value": n_db / dt, "unit": "vectors/s", "vectors": n_db, "seconds": dt, "host_batch": 4 * batch,
+            "part_file_writer": "parallel deflate while encoding (qinco_amd.encode_db.PartFileWriter, 8 threads); "
+                                f"np.savez_compressed of the same codes at the end would add {dt_ref_writer:.2f} s",
+            "np_savez_compressed_s": dt_ref_writer,
             "resident_value": n_res / dt_res, "host_over_resident": (n_db / dt) / (n_res / dt_res),
             "codes_equal_to_resident_path": same, "input": "uint8 .bvecs",
             "file_bytes": n_db * (cfg.D + 4), "file_write_s": t_write, "part_file_bytes": part_bytes,
-            "path": "np.memmap (strided uint8 rows) -> encode_database -> QINCoHIP.__call__ -> qinco_encode_host -> np.savez_compressed "
-                    "(includes the int64 part-file compression the reference also does, search_tasks.py:125-131)"}
+            "path": "np.memmap (strided uint8 rows) -> encode_database -> QINCoHIP.__call__ -> qinco_encode_host -> part file in the "
+                    "reference's format (deflated int64 codes, search_tasks.py:125-131)"}
 
 
 def main():
@@ -481,7 +487,8 @@ def main():
             for key, fn in (("c1", lambda: leg_workload(torch, dev, "C1", 3, 16384, oracle_sample=256)),
                             ("c3", lambda: leg_workload(torch, dev, "C3", 2, 16384)),
                             ("c4", lambda: leg_workload(torch, dev, "C4", 2, 16384)),
-                            ("encode_db_bvecs", lambda: leg_encode_db_bvecs(torch, dev, args.bvecs_vectors, 16384))):
+                            ("encode_db_bvecs", lambda: leg_encode_db_bvecs(torch, dev, args.bvecs_vectors, 16384)),
+                            ("encode_db_bvecs_qinco2S", lambda: leg_encode_db_bvecs(torch, dev, args.bvecs_vectors, 16384, "S"))):
                 try:        # a leg can never take the headline down with it
                     out[key] = fn()
                 except Exception as e:                        # noqa: BLE001

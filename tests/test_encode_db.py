@@ -124,3 +124,32 @@ def test_sharded_encode_equals_single_process_gloo(tmp_path, world, n):
     for r in range(world):
         s, e = shard_bounds(n, world, r)
         assert len(np.load(tmp_path / f"db.part_{r}.npz")["codes"]) == e - s
+
+
+def test_part_file_writer_is_the_reference_format(tmp_path):
+    """PartFileWriter (parallel, incremental deflate) must produce what np.savez_compressed(path, codes=...) means to every
+    reader: np.load gives the same int64 array, zipfile's CRC check passes, sizes beyond one chunk and exact chunk boundaries
+    included; and encode_database writes the same part file with and without it."""
+    import zipfile
+    from qinco_amd.encode_db import EncodedDBIterator, PartFileWriter, encode_database
+    rs = np.random.RandomState(0)
+    hdr = 128
+    for rows in (0, 1, 777, 70001, (2 * PartFileWriter.CHUNK - hdr) // 64):
+        c = rs.randint(0, 256, (rows, 8)).astype(np.int64)
+        p = str(tmp_path / f"w{rows}.npz")
+        w = PartFileWriter(p, rows, 8, threads=3)
+        for i in range(0, rows, 20000):
+            w.add(c[i:i + 20000])
+        w.close()
+        got = np.load(p)["codes"]
+        assert got.dtype == np.int64 and got.shape == c.shape and np.array_equal(got, c)
+        assert zipfile.ZipFile(p).testzip() is None and zipfile.ZipFile(p).namelist() == ["codes.npy"]
+    model = OracleModel("tiny_proj_beam")
+    from qinco_amd import synth_vectors
+    db = synth_vectors(model.cfg, model.sd, 130, seed=2)
+    outs = []
+    for threads in (0, 4):
+        out = str(tmp_path / f"t{threads}" / "db.npz")
+        encode_database(model, db, out, K=model.cfg.K, M=model.cfg.M, D=model.cfg.D, batch=50, writer_threads=threads)
+        outs.append(EncodedDBIterator(out).load_all())
+    assert np.array_equal(outs[0], outs[1])

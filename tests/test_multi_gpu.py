@@ -178,9 +178,10 @@ def test_bench_driver_line_carries_the_metric_grid():
     for k, M, D in (("c3", 16, 128), ("c4", 8, 768)):
         assert "error" not in rec[k], rec[k]
         assert rec[k]["M"] == M and rec[k]["D"] == D and rec[k]["value"] > 0 and 0.5 < rec[k]["roofline"]["frac_executed"] <= 1.0
-    db = rec["encode_db_bvecs"]
-    assert "error" not in db, db
-    assert db["vectors"] == 40000 and db["codes_equal_to_resident_path"] and db["value"] > 0 and db["resident_value"] > 0
+    for key in ("encode_db_bvecs", "encode_db_bvecs_qinco2S"):
+        db = rec[key]
+        assert "error" not in db, db
+        assert db["vectors"] == 40000 and db["codes_equal_to_resident_path"] and db["value"] > 0 and db["resident_value"] > 0
     assert "kernel_instances" in rec["config"]
 
 

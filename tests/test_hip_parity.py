@@ -375,6 +375,28 @@ def test_fused_preselection_launch_is_bit_identical_to_the_two_kernels(model, D,
     plain.close()
 
 
+@pytest.mark.parametrize("model,D", [("qinco2-S", 128), ("qinco2-M", 128), ("qinco1", 128)])
+def test_codes_do_not_depend_on_max_batch(model, D):
+    """The same vectors through handles of different max_batch take different kernels (small passes: cooperative / fused
+    pre-selection + xproj; large passes: the streaming kernels) and different tilings of the batch -- codes and tracked
+    reconstructions must be the same bits: a vector's result is a function of the vector and the model only."""
+    import torch
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    from qinco_amd.config import preset
+    cfg = preset(model, D=D, M=4, B=8) if model != "qinco1" else preset(model, D=D, M=4, L=4)
+    sd = synth_state_dict(cfg, 5150)
+    n = 20000
+    x = torch.from_numpy(synth_vectors(cfg, sd, n, seed=51)).cuda()
+    out = []
+    for mb in (1000, 4096, 20000):
+        eng = QincoEngine(cfg, sd, max_batch=mb)
+        c, h = eng.encode(x, return_xhat=True)
+        out.append((c.cpu().numpy(), h.cpu().numpy()))
+        eng.close()
+    for c, h in out[1:]:
+        assert np.array_equal(c, out[0][0]) and np.array_equal(h, out[0][1])
+
+
 def test_errors_mirror_reference(engines):
     from qinco_amd import QincoEngine, synth_state_dict
     cfg, sd, eng = engines("tiny_id_qinco1")
@@ -643,26 +665,27 @@ def test_model_exposes_inner_model_attribute_path():
     assert len(model.get_codebooks_refs()) == cfg.M
 
 
-def test_bench_shape_batch_matches_oracle_on_scattered_rows():
-    """bench.py's configuration itself (C2, 16 384 vectors in ONE pass at max_batch = 16 384: 2 M MLP rows per launch):
-    64 rows scattered over the batch against the oracle."""
+@pytest.mark.parametrize("wl,nrows", [("C2", 64), ("C1", 48), ("C3", 24), ("C4", 24)])
+def test_bench_shape_batch_matches_oracle_on_scattered_rows(wl, nrows):
+    """bench.py's configurations themselves (every BASELINE config at 16 384 vectors in ONE pass at max_batch = 16 384: up to
+    4 M MLP rows per launch): rows scattered over the batch against the oracle."""
     from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
     from qinco_amd.config import BASELINE_CONFIGS
-    cfg = BASELINE_CONFIGS["C2"]
+    cfg = BASELINE_CONFIGS[wl]
     sd = synth_state_dict(cfg, 1236)
     n = 16384
     x = synth_vectors(cfg, sd, n, seed=31337)
     eng = QincoEngine(cfg, sd, max_batch=n)
     codes, xhat_n = eng.encode(x, return_xhat=True)
     rows = np.unique(np.concatenate([[0, 1, 127, 128, n // 2 - 1, n // 2, n - 2, n - 1],
-                                     np.random.RandomState(5).randint(0, n, 56)]))
+                                     np.random.RandomState(5).randint(0, n, nrows - 8)]))
     oracle = make_oracle(cfg, sd)
     want = oracle(x[rows], step="encode").T
-    nbad = assert_only_near_ties(oracle, x[rows], codes[rows], want, NEAR_TIE, "C2 @ 16384")
+    nbad = assert_only_near_ties(oracle, x[rows], codes[rows], want, NEAR_TIE, f"{wl} @ 16384")
     ok = (codes[rows] == want).all(axis=1)
     ref = (oracle(want.T, step="decode") - oracle.data_mean) / oracle.data_std
     assert rel_err(xhat_n[rows][ok], ref[ok]) < REL_TOL
-    print(f"C2 batch 16384: {nbad} of {len(rows)} sampled rows on a tie")
+    print(f"{wl} batch 16384: {nbad} of {len(rows)} sampled rows on a tie")
     eng.close()
 
 

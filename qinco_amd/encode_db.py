@@ -85,6 +85,48 @@ def encode_shard(model: Callable, db_vecs, start: int, end: int, batch: int = 65
 # ---------------------------------------------------------------------------------------------
 # part-file writer: the reference's format, written as fast as the GPU produces codes
 # ---------------------------------------------------------------------------------------------
+def _gf2_times(mat, vec):
+    s, i = 0, 0
+    while vec:
+        if vec & 1:
+            s ^= mat[i]
+        vec >>= 1
+        i += 1
+    return s
+
+
+def _gf2_square(mat):
+    return [_gf2_times(mat, m) for m in mat]
+
+
+_CRC_SHIFT = {}     # len -> the 32 x 32 GF(2) operator that advances a CRC over `len` zero bytes
+
+
+def _crc_shift_operator(n: int):
+    op = _CRC_SHIFT.get(n)
+    if op is None:
+        ident = [1 << i for i in range(32)]
+        op = ident
+        power = _gf2_square(_gf2_square(_gf2_square([0xEDB88320] + [1 << i for i in range(31)])))   # one zero BYTE
+        k = n
+        while k:
+            if k & 1:
+                op = [_gf2_times(power, col) for col in op]
+            power = _gf2_square(power)
+            k >>= 1
+        _CRC_SHIFT[n] = op
+    return op
+
+
+def crc32_combine(crc1: int, crc2: int, len2: int) -> int:
+    """CRC-32 of A + B from crc32(A), crc32(B), len(B) (what zlib's crc32_combine does; Python's zlib does not export it): lets
+    every chunk's CRC be computed on the worker thread that deflates it.  The operator of a length is cached (all chunks
+    but the last have the same one)."""
+    if len2 <= 0:
+        return crc1
+    return _gf2_times(_crc_shift_operator(len2), crc1) ^ crc2
+
+
 class PartFileWriter:
     """`np.savez_compressed(path, codes=<(N, M) int64>)` (search_tasks.py:125-131) without its cost.
 
@@ -129,25 +171,24 @@ class PartFileWriter:
         self._z64_at = self._f.tell()
         self._f.write(z64)
 
-    def _deflate(self, data: bytes, last: bool) -> bytes:
+    def _deflate(self, data: bytes, last: bool):
         import zlib
         co = zlib.compressobj(self.level, zlib.DEFLATED, -15)
-        return co.compress(data) + co.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH)
+        return co.compress(data) + co.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH), zlib.crc32(data), len(data)
 
     def _drain(self, everything: bool):
         """Finished chunks at the head of the queue go to disk (in order); at most `_depth` chunks are kept in flight."""
         while self._futs and (everything or self._futs[0].done() or len(self._futs) > self._depth):
-            blob = self._futs.pop(0).result()
+            blob, crc, n = self._futs.pop(0).result()
             self._f.write(blob)
             self._csize += len(blob)
+            self._crc = crc32_combine(self._crc, crc, n)
 
     def _submit(self, last: bool):
-        import zlib
         while len(self._buf) >= self.CHUNK or (last and self._buf):
             take = bytes(self._buf[: self.CHUNK])
             del self._buf[: self.CHUNK]
             fin = last and not self._buf
-            self._crc = zlib.crc32(take, self._crc)
             self._usize += len(take)
             self._futs.append(self._pool.submit(self._deflate, take, fin))
             self._finished = fin

@@ -49,9 +49,10 @@ def numa_cpus_of_gpu(dev_index: int, sysfs: str = "/sys") -> Optional[tuple]:
         return None
 
 
-def bind_to_gpu_numa(dev_index: int, local_rank: int = 0, ranks_on_node: int = 1) -> Optional[dict]:
-    """Restrict this process to the CPUs of the GPU's NUMA node (intersected with what it is already allowed to use), and --
-    when several ranks share that node -- to this rank's slice of them.  Returns a description or None (nothing changed)."""
+def bind_to_gpu_numa(dev_index: int) -> Optional[dict]:
+    """Restrict this process to the CPUs of the GPU's NUMA node (intersected with what it is already allowed to use; ranks
+    whose GPUs share a node share its cores -- a rank runs one driving thread plus the part-file writer's pool).  Returns a
+    description or None (nothing changed)."""
     if not hasattr(os, "sched_setaffinity"):
         return None
     info = numa_cpus_of_gpu(dev_index)

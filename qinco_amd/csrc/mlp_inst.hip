@@ -50,7 +50,8 @@ hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::Mlp
 
 #ifdef QINCO_INSTANCE_MODULE
 // Built on demand as a shared object of its own (qinco_amd.build.ensure_instance) and registered with qinco_load_instance:
-// v = {D, De, Dh, P, VAR, 0}, fns = {mlp launcher, xproj launcher}; returns sizeof(MlpArgs) as the source-version check.
+// v = {D, De, Dh, P, VAR, 0}, fns = {mlp launcher, xproj launcher}; returns the sizes of the two argument blocks as the
+// source-version check (a module built against another csrc/mlp_args.hpp must not be launched).
 extern "C" hipError_t QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::XprojArgs* a, hipStream_t stream);
 extern "C" __attribute__((visibility("default"))) int qinco_instance_info(int* v, void** fns) {
   v[0] = QD;
@@ -60,7 +61,7 @@ extern "C" __attribute__((visibility("default"))) int qinco_instance_info(int* v
   v[4] = QVAR;
   fns[0] = reinterpret_cast<void*>(&QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR));
   fns[1] = reinterpret_cast<void*>(&QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR));
-  return (int)sizeof(qinco::MlpArgs);
+  return (int)((sizeof(qinco::MlpArgs) << 16) | sizeof(qinco::XprojArgs));
 }
 #endif
 

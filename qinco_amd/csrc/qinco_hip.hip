@@ -635,11 +635,11 @@ extern "C" int qinco_load_instance(const char* path) {
   }
   int32_t v[6] = {0, 0, 0, 0, 0, 0};
   void* fns[2] = {nullptr, nullptr};
-  const int abi = info(v, fns);
-  if (abi != (int)sizeof(MlpArgs) || !fns[0] || !fns[1]) {
+  const int abi = info(v, fns), want_abi = (int)((sizeof(MlpArgs) << 16) | sizeof(XprojArgs));
+  if (abi != want_abi || !fns[0] || !fns[1]) {
     dlclose(so);
-    return fail(QINCO_ERR_INVALID, "qinco_load_instance: %s was built against another version of csrc/mlp_args.hpp (%d vs %d)", path, abi,
-                (int)sizeof(MlpArgs));
+    return fail(QINCO_ERR_INVALID, "qinco_load_instance: %s was built against another version of csrc/mlp_args.hpp (0x%x vs 0x%x)", path,
+                abi, want_abi);
   }
   for (const MlpInstance& i : g_loaded)
     if (i.D == v[0] && i.De == v[1] && i.Dh == v[2] && i.P == v[3] && i.var == v[4]) return QINCO_OK;   // already there

@@ -153,3 +153,21 @@ def test_part_file_writer_is_the_reference_format(tmp_path):
         encode_database(model, db, out, K=model.cfg.K, M=model.cfg.M, D=model.cfg.D, batch=50, writer_threads=threads)
         outs.append(EncodedDBIterator(out).load_all())
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_numa_cpu_set_of_a_gpu_from_sysfs(tmp_path, monkeypatch):
+    """qinco_amd.affinity: PCI address -> sysfs numa_node -> node cpulist (the lookup bench.py's ranks bind themselves with);
+    anything missing is "leave the affinity alone", never an error."""
+    from qinco_amd import affinity
+    assert affinity._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    (tmp_path / "bus/pci/devices/0000:c1:00.0").mkdir(parents=True)
+    (tmp_path / "bus/pci/devices/0000:c1:00.0/numa_node").write_text("1\n")
+    (tmp_path / "devices/system/node/node1").mkdir(parents=True)
+    (tmp_path / "devices/system/node/node1/cpulist").write_text("64-127,192-255\n")
+    monkeypatch.setattr(affinity, "gpu_pci_address", lambda i: "0000:c1:00.0" if i == 0 else None)
+    node, cpus = affinity.numa_cpus_of_gpu(0, sysfs=str(tmp_path))
+    assert node == 1 and len(cpus) == 128 and cpus[0] == 64 and cpus[-1] == 255
+    assert affinity.numa_cpus_of_gpu(1, sysfs=str(tmp_path)) is None          # no PCI address
+    (tmp_path / "bus/pci/devices/0000:c1:00.0/numa_node").write_text("-1\n")     # single-node box
+    assert affinity.numa_cpus_of_gpu(0, sysfs=str(tmp_path)) is None
+    assert affinity.bind_to_gpu_numa(0) is None or isinstance(affinity.bind_to_gpu_numa(0), dict)

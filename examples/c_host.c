@@ -7,8 +7,9 @@
  * seeded generator in the reference's state_dict layout (qinco/model/qinco_base.py:229-260), then does what
  * qinco/search/search_tasks.py:85-137 does with the reference's model object: encode a "database" from host memory
  * (qinco_encode_host), gather the shard's codes (qinco_gather_codes, world = 1: no communicator), decode them
- * (qinco_decode_host) and report the reconstruction error next to the error of the first codebook alone -- the neural steps
- * must improve on it -- and the self-consistency of encode's tracked reconstruction with decode.
+ * (qinco_decode_host) and report the reconstruction error next to the error of RANDOM code rows decoded by the same model -- the
+ * beam search must beat them by a wide margin (the weights are random, so this says nothing about quantisation quality, only
+ * that encode searches and decode inverts it) -- and the self-consistency of encode's tracked reconstruction with decode.
  * The device-pointer entry points need a HIP allocation; they are resolved from libamdhip64 with dlsym so that this file needs
  * no HIP headers. */
 #include <dlfcn.h>
@@ -91,6 +92,10 @@ int main(void) {
   float* dec = (float*)malloc((size_t)N * D * sizeof(float));
   CHECK(qinco_encode_host(h, x, QINCO_X_F32, 0, N, codes, QINCO_CODE_U8, xhat_n, 0));     /* 3 passes of max_batch rows */
   CHECK(qinco_decode_host(h, codes, QINCO_CODE_U8, N, dec, 0));
+  uint8_t* rcodes = (uint8_t*)malloc((size_t)N * M);
+  float* rdec = (float*)malloc((size_t)N * D * sizeof(float));
+  for (size_t i = 0; i < (size_t)N * M; ++i) rcodes[i] = (uint8_t)(uniform() * K);
+  CHECK(qinco_decode_host(h, rcodes, QINCO_CODE_U8, N, rdec, 0));
 
   /* the end-of-job collective on device buffers (one rank: a device copy) */
   void* hip = dlopen("libamdhip64.so", RTLD_NOW | RTLD_GLOBAL);
@@ -111,21 +116,20 @@ int main(void) {
 
   double err = 0.0, err0 = 0.0, self = 0.0, scale_x = 0.0;
   for (int i = 0; i < N; ++i) {
-    const float* c0 = cb[0] + (size_t)codes[(size_t)i * M] * D;
     for (int j = 0; j < D; ++j) {
-      const double xi = x[(size_t)i * D + j], xn = (xi - mean[j]) / 2.0;
-      const double e = xi - dec[(size_t)i * D + j], e0 = xn - c0[j];
+      const double xi = x[(size_t)i * D + j];
+      const double e = xi - dec[(size_t)i * D + j], e0 = xi - rdec[(size_t)i * D + j];
       const double s = (double)xhat_n[(size_t)i * D + j] * 2.0 + mean[j] - dec[(size_t)i * D + j];
       err += e * e;
-      err0 += 4.0 * e0 * e0;
+      err0 += e0 * e0;
       self = fmax(self, fabs(s));
       scale_x = fmax(scale_x, fabs(xi));
     }
   }
   err /= N;
   err0 /= N;
-  printf("c_host: %s | %d vectors, MSE %.3f (step 0 alone %.3f), encode-vs-decode reconstruction differs by %.2e relative, gather %s\n", desc,
+  printf("c_host: %s | %d vectors, MSE %.3f (random code rows: %.3f), encode-vs-decode reconstruction differs by %.2e relative, gather %s\n", desc,
          N, err, err0, self / scale_x, gathered_ok == 1 ? "ok" : gathered_ok == 0 ? "MISMATCH" : "skipped");
   CHECK(qinco_destroy(h));
-  return (err < err0 && self / scale_x < 1e-5 && gathered_ok != 0) ? 0 : 3;
+  return (err < 0.75 * err0 && self / scale_x < 1e-5 && gathered_ok != 0) ? 0 : 3;
 }

@@ -168,6 +168,38 @@ def test_split_f16_checks_itself_at_create_and_at_run_time(split_engines):
     e3.close()
 
 
+def test_split_f16_on_the_reference_trained_checkpoint_at_scale():
+    """65 536 held-out rows of the clustered byte distribution through the checkpoint the reference trained, fp32 path against
+    split form: the rows that differ are rare, sit on oracle near-ties (a dozen of them replayed), and the MSE agrees to 1e-6."""
+    import torch
+    from conftest import GOLDEN
+    from make_trained import clustered_rows
+    from qinco_amd import QincoEngine
+    from qinco_amd.checkpoint import load_checkpoint
+    cfg, sd = load_checkpoint(str(GOLDEN / "trained_qinco2S.pt"))
+    n = 65536
+    x = clustered_rows("u8", n, cfg.D, 2101, part=2)              # uint8, a different draw from the fixtures' (part 1)
+    xd = torch.from_numpy(x).cuda()
+    res = {}
+    for split in (False, True):
+        eng = QincoEngine(cfg, sd, max_batch=16384, split_f16=split)
+        codes = eng.encode(xd)
+        dec = eng.decode(codes)
+        err = float(((xd.float() - dec) ** 2).sum(-1).mean())
+        res[split] = (codes.cpu().numpy(), err, eng.split_stats())
+        eng.close()
+    bad = np.nonzero((res[True][0] != res[False][0]).any(axis=1))[0]
+    print(f"trained qinco2-S, {n} vectors: {len(bad)} rows differ between split and fp32; MSE {res[False][1]:.4f} / {res[True][1]:.4f}; "
+          f"split stats {res[True][2]}")
+    assert len(bad) <= n // 2000 and abs(res[True][1] - res[False][1]) / res[False][1] < 1e-6
+    if len(bad):
+        sel = bad[:12]
+        oracle = make_oracle(cfg, sd)
+        want = oracle(x[sel], step="encode").T
+        assert_only_near_ties(oracle, x[sel], res[True][0][sel], want, NEAR_TIE, "trained split")
+        assert_only_near_ties(oracle, x[sel], res[False][0][sel], want, NEAR_TIE, "trained fp32")
+
+
 def test_split_f16_ragged_batches_and_overflow_flag(split_engines):
     """Row counts that are not multiples of the 32-row tile / of max_batch give the codes of the full batch; a model whose
     activations leave the fp16 range is reported (QINCO_ERR_RANGE -> IndexError), not encoded from NaNs."""

@@ -68,3 +68,23 @@ def case_model(name: str):
     if c.regime:
         sd = apply_regime(c.cfg, sd, c.regime, c.seed)
     return c.cfg, sd
+
+
+def clustered_rows(kind: str, n: int, D: int, seed: int, part: int = 0) -> np.ndarray:
+    """Synthetic stand-in for a descriptor dataset: 48 clusters with their own low-rank anisotropic covariance, Laplace
+    (heavy-tailed) coefficients, a per-dimension offset profile.  kind "u8": SIFT-like non-negative bytes; kind "small":
+    float rows of magnitude ~0.1 (deep1M / contriever-like normalisation constants).  The mixture is a function of `seed`;
+    `part` selects an independent draw of rows from it (0 = the training rows, others = held-out rows for the fixtures)."""
+    rs = np.random.RandomState(seed)
+    nc, r = 48, 12
+    centres = rs.randn(nc, D) * 0.9
+    bases = rs.randn(nc, r, D) / np.sqrt(r) * (0.3 + 1.4 * rs.rand(nc, r, 1))
+    profile_u8 = 12.0 + 55.0 * rs.rand(D) ** 2           # per-dimension offset: a few tens, some dimensions much larger
+    profile_small = 0.02 * rs.randn(D)
+    rs = np.random.RandomState(seed + 10007 * (part + 1))
+    which = rs.randint(0, nc, n)
+    coef = rs.laplace(size=(n, r)) * 0.8
+    z = centres[which] + np.einsum("nr,nrd->nd", coef, bases[which]) + 0.25 * rs.randn(n, D)
+    if kind == "u8":
+        return np.clip(np.rint(profile_u8 + 33.0 * z), 0, 255).astype(np.uint8)
+    return (profile_small + 0.085 * z).astype(np.float32)

@@ -30,8 +30,7 @@ from qinco.model import QINCo, QINCoInferenceWrapper  # noqa: E402  (the referen
 from qinco.model.qinco_base import IVFBook  # noqa: E402
 
 sys.path.insert(0, str(HERE))
-from cases import CASES, case_model  # noqa: E402  (the case table, shared with tests/conftest.py)
-from make_trained import clustered_rows  # noqa: E402
+from cases import CASES, case_model, clustered_rows  # noqa: E402  (the case table, shared with tests/conftest.py)
 from qinco_amd.config import QincoConfig  # noqa: E402
 from qinco_amd.synth import regime_vectors, synth_codes, synth_vectors  # noqa: E402
 from oracle.qinco_oracle import OracleQINCo  # noqa: E402

@@ -173,7 +173,7 @@ def test_split_f16_on_the_reference_trained_checkpoint_at_scale():
     split form: the rows that differ are rare, sit on oracle near-ties (a dozen of them replayed), and the MSE agrees to 1e-6."""
     import torch
     from conftest import GOLDEN
-    from make_trained import clustered_rows
+    from cases import clustered_rows
     from qinco_amd import QincoEngine
     from qinco_amd.checkpoint import load_checkpoint
     cfg, sd = load_checkpoint(str(GOLDEN / "trained_qinco2S.pt"))

@@ -129,6 +129,27 @@ def self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def call_with_timeout(fn, seconds):
+    """Run fn() on a helper thread; TimeoutError if it has not returned after `seconds` (a wedged RCCL call must not take
+    the whole run with it: the caller falls back to part files and the process leaves through os._exit at the end)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as e:                            # noqa: BLE001 -- re-raised on the caller's thread
+            box["error"] = e
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        raise TimeoutError(f"no answer after {seconds:.0f} s")
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
 def synth_batch_device(torch, cfg, mean_t, std, n, seed, dev):
     """x = mean + std * N(0, I) (the S0 inputs of SURVEY.md 8d), drawn on the device from a seeded generator."""
     g = torch.Generator(device=dev)
@@ -293,6 +314,8 @@ def main():
     ap.add_argument("--no-affinity", action="store_true", help="do not bind the rank to its GPU's NUMA node")
     ap.add_argument("--split-f16", action="store_true",
                     help="NOT the driver's configuration: run the whole bench (any --gpus) on the opt-in split-fp16 form; the line says so in dtype / config")
+    ap.add_argument("--rccl-timeout", type=float, default=180.0,
+                    help="seconds an RCCL call (communicator creation, the gather) may take before the run falls back to part files")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="payload gather: nccl = RCCL over xGMI (one GPU per rank). gloo is a test hook: ranks may share a GPU.")
     args = ap.parse_args()
@@ -329,6 +352,7 @@ def main():
 
     # control plane on gloo (always works on one node), payload on RCCL when asked for and available
     data_group, data_note = None, None
+    wedged = False            # an RCCL call timed out: its thread is still stuck, so the process must leave through os._exit
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -336,10 +360,15 @@ def main():
             ok = 1
             try:
                 data_group = dist.new_group(backend="nccl", device_id=dev)
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe, group=data_group)      # forces communicator creation now, outside the timed region
-                torch.cuda.synchronize(dev)
-            except Exception as e:                            # noqa: BLE001 -- any failure: part files instead
+
+                def probe_rccl():                             # forces communicator creation now, outside the timed region
+                    torch.cuda.set_device(dev_index)
+                    probe = torch.ones(1, device=dev)
+                    dist.all_reduce(probe, group=data_group)
+                    torch.cuda.synchronize(dev)
+                call_with_timeout(probe_rccl, args.rccl_timeout)
+            except BaseException as e:                        # noqa: BLE001 -- any failure or a hang: part files instead
+                wedged = wedged or isinstance(e, TimeoutError)
                 ok, data_note = 0, f"RCCL unavailable on rank {rank}: {type(e).__name__}: {e}"[:300]
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # gloo: everybody agrees on the payload path
@@ -381,11 +410,17 @@ def main():
         batches = [stream_batch(rank * K + s) for s in range(K)]
         my_vecs = K * args.batch
 
+    def device_sync():        # (a wedged RCCL kernel would make a device-wide synchronize wait forever: the compute stream only)
+        if wedged:
+            torch.cuda.current_stream(dev).synchronize()
+        else:
+            torch.cuda.synchronize(dev)
+
     def barrier():
-        torch.cuda.synchronize(dev)
+        device_sync()
         if world > 1:
             dist.barrier()                                    # gloo
-        torch.cuda.synchronize(dev)
+        device_sync()
 
     for xb in warm:
         eng.encode(xb, code_dtype=np.uint8)
@@ -410,8 +445,12 @@ def main():
                 raise RuntimeError("forced by QINCO_BENCH_FORCE_GATHER_ERROR")
             if data_group is not None:
                 bucket = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-                dist.gather(pad, bucket, dst=0, group=data_group)
-                torch.cuda.synchronize(dev)
+
+                def gather_rccl():
+                    torch.cuda.set_device(dev_index)
+                    dist.gather(pad, bucket, dst=0, group=data_group)
+                    torch.cuda.synchronize(dev)
+                call_with_timeout(gather_rccl, args.rccl_timeout)
                 gather_how = "rccl"
             elif args.backend == "gloo":
                 pad_c = pad.cpu()
@@ -422,7 +461,8 @@ def main():
                 raise RuntimeError(data_note or "no RCCL group")
             if rank == 0:
                 assert len(bucket) == world and all(b.shape == pad.shape for b in bucket)
-        except Exception as e:                                # noqa: BLE001 -- fail soft: the reference's own part files
+        except BaseException as e:                            # noqa: BLE001 -- fail soft: the reference's own part files
+            wedged = wedged or isinstance(e, TimeoutError)
             outdir = os.environ.get("QINCO_BENCH_PARTS", tempfile.gettempdir())
             np.savez_compressed(os.path.join(outdir, f"qinco_bench_codes.part_{rank}.npz"), codes=mine.cpu().numpy())
             gather_how = f"failed: {type(e).__name__}: {e}"[:300] + " -> part files"
@@ -498,9 +538,13 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    eng.close()
     if world > 1:
         dist.barrier()
+    if wedged:                # a helper thread is still inside RCCL: skip every destructor that could wait for it
+        sys.stderr.flush()
+        os._exit(0)
+    eng.close()
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -441,7 +441,10 @@ def main():
         pad = torch.zeros((longest, cfg.M_total), dtype=torch.uint8, device=dev)
         pad[: len(mine)] = mine
         try:
-            if os.environ.get("QINCO_BENCH_FORCE_GATHER_ERROR"):      # test hook (tests/test_multi_gpu.py): the fail-soft path
+            hook = os.environ.get("QINCO_BENCH_FORCE_GATHER_ERROR")   # test hook (tests/test_multi_gpu.py): the fail-soft paths
+            if hook == "hang":
+                call_with_timeout(lambda: time.sleep(1e6), args.rccl_timeout)
+            elif hook:
                 raise RuntimeError("forced by QINCO_BENCH_FORCE_GATHER_ERROR")
             if data_group is not None:
                 bucket = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None

@@ -151,18 +151,21 @@ def test_bench_strong_scaling_splits_one_database():
     assert abs(rec["value"] - 1636 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-6
 
 
-def test_bench_fails_soft_when_rccl_is_unavailable():
-    """--backend nccl with more ranks than GPUs is refused up front; but an RCCL that fails at run time must not lose the
-    run: the ranks write part files and the line says so.  Simulated by pointing the payload path at a backend that cannot
-    gather (QINCO_BENCH_FORCE_GATHER_ERROR, a test hook read by bench.py only)."""
+@pytest.mark.parametrize("mode", ["1", "hang"], ids=["raises", "hangs"])
+def test_bench_fails_soft_when_rccl_is_unavailable(mode):
+    """--backend nccl with more ranks than GPUs is refused up front; but an RCCL that fails -- or hangs -- at run time must
+    not lose the run: the ranks write part files and the line says so.  Simulated with a test hook read by bench.py only
+    (QINCO_BENCH_FORCE_GATHER_ERROR = "1": the gather raises; "hang": it never returns and --rccl-timeout ends the wait)."""
     import os
-    os.environ["QINCO_BENCH_FORCE_GATHER_ERROR"] = "1"
+    os.environ["QINCO_BENCH_FORCE_GATHER_ERROR"] = mode
     try:
-        rec = _bench("--gpus", "2", "--backend", "gloo", "--workload", "C1", "--batch", "256", "--steps", "1", "--warmup", "0")
+        rec = _bench("--gpus", "2", "--backend", "gloo", "--workload", "C1", "--batch", "256", "--steps", "1", "--warmup", "0",
+                     "--rccl-timeout", "3")
     finally:
         del os.environ["QINCO_BENCH_FORCE_GATHER_ERROR"]
     mg = rec["multi_gpu"]
     assert rec["value"] > 0 and mg["gather"].startswith("failed:") and "part files" in mg["gather"]
+    assert ("TimeoutError" in mg["gather"]) == (mode == "hang")
     assert not mg["gather_ok_on_all_ranks"] and all(v > 0 for v in mg["per_rank_encode_vectors_per_s"])
 
 

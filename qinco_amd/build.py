@@ -147,8 +147,16 @@ def ensure_instance(D: int, De: int, Dh: int, verbose: bool = False) -> Path | N
         return None
     Dp, Dep, Dhp = (int(v) for v in out3)
     P, var = instance_plan(Dp, Dep, Dhp)
-    INST.mkdir(exist_ok=True)
-    so = INST / f"inst_{Dp}_{Dep}_{Dhp}_{P}_{var}.so"
+    inst_dir = INST
+    try:
+        inst_dir.mkdir(exist_ok=True)
+        probe = inst_dir / ".writable"
+        probe.touch()
+        probe.unlink()
+    except OSError:       # a read-only installation: the user's cache directory instead of the package directory
+        inst_dir = Path(os.environ.get("XDG_CACHE_HOME", Path.home() / ".cache")) / "qinco_amd" / "instances"
+        inst_dir.mkdir(parents=True, exist_ok=True)
+    so = inst_dir / f"inst_{Dp}_{Dep}_{Dhp}_{P}_{var}.so"
     cmd = [c for c in instance_cmd("hipcc", (Dp, Dep, Dhp, P, var), so, extra=("-DQINCO_INSTANCE_MODULE", "-shared")) if c != "-c"]
     if not _fresh(so, cmd[1:]):
         cmd[0] = hipcc()          # raises when there is no compiler: a new geometry cannot be served on this machine

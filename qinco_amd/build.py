@@ -117,12 +117,13 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
 
 def instance_plan(Dp: int, Dep: int, Dhp: int) -> tuple[int, int]:
     """(P, VAR) of the kernel form that serves a padded shape (csrc/shapes.def explains the VAR bits): the 32-row kernel with the
-    folded head -- two workgroups per CU on the short shapes -- while its activations fit the register file (De, Dh <= 384),
-    else the 16-row tile kernel."""
+    folded head -- two workgroups per CU on the short shapes -- while its activations fit the register file (z = De / 2 VGPRs,
+    y = Dh / 2 AGPRs per lane: De <= 384, Dh <= 512, De + Dh <= 768; (256, 512) compiles to 236 VGPRs + 256 AGPRs, no
+    scratch), else the 16-row tile kernel."""
     if Dp > 1024:
         raise NotImplementedError(f"no kernel form for D={Dp}: the per-group pre-GEMM keeps a group's D / 32 input blocks in registers "
                                   "(D <= 1024; the reference's widest dataset is 768)")
-    if Dep <= 384 and Dhp <= 384:
+    if Dep <= 384 and Dhp <= 512 and Dep + Dhp <= 768:
         return (48, 380) if (Dep <= 128 and Dhp <= 256) else (48, 124)
     if Dep <= 768 and max(Dep, Dhp) <= 1024:
         return (48, 196)

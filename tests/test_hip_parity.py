@@ -354,7 +354,8 @@ def test_input_formats(engines):
 
 
 @pytest.mark.parametrize("kw", [
-    dict(D=100, de=256, dh=512, L=3, A=8, B=4),                        # the 16-row tile form, D padded 100 -> 128
+    dict(D=100, de=256, dh=512, L=3, A=8, B=4),                        # D padded 100 -> 128; y fills all 256 AGPRs of the 32-row form
+    dict(D=100, de=512, dh=384, L=2, A=8, B=4),                        # De > 384: the 16-row tile form
     dict(D=100, de=None, dh=200, L=2, A=0, B=1, qinco1_mode=True),     # QINCo1-style, De = D = 100, Dh 200 -> 224
     dict(D=100, de=128, dh=256, L=2, A=8, B=4),                        # padding must not turn the projections into identities
     dict(D=64, de=96, dh=160, L=2, A=8, B=2),                          # multiples of 32 that shapes.def does not list

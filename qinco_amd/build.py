@@ -157,16 +157,30 @@ def ensure_instance(D: int, De: int, Dh: int, verbose: bool = False) -> Path | N
     except OSError:       # a read-only installation: the user's cache directory instead of the package directory
         inst_dir = Path(os.environ.get("XDG_CACHE_HOME", Path.home() / ".cache")) / "qinco_amd" / "instances"
         inst_dir.mkdir(parents=True, exist_ok=True)
-    so = inst_dir / f"inst_{Dp}_{Dep}_{Dhp}_{P}_{var}.so"
-    cmd = [c for c in instance_cmd("hipcc", (Dp, Dep, Dhp, P, var), so, extra=("-DQINCO_INSTANCE_MODULE", "-shared")) if c != "-c"]
-    if not _fresh(so, cmd[1:]):
-        cmd[0] = hipcc()          # raises when there is no compiler: a new geometry cannot be served on this machine
+    # the encode instance, and -- for the folded 32-row forms -- the un-folded twin decode runs on (one row per group shares
+    # nothing, so the folded head is pure overhead there: DESIGN.md 3.1); compiled side by side
+    variants = [var] + ([var & ~(16 | 32)] if (var & 16) and not (var & 128) else [])
+    jobs = []
+    for v in variants:
+        so = inst_dir / f"inst_{Dp}_{Dep}_{Dhp}_{P}_{v}.so"
+        cmd = [c for c in instance_cmd("hipcc", (Dp, Dep, Dhp, P, v), so, extra=("-DQINCO_INSTANCE_MODULE", "-shared")) if c != "-c"]
+        jobs.append((so, cmd, _fresh(so, cmd[1:])))
+    todo = [(so, cmd) for so, cmd, fresh in jobs if not fresh]
+    if todo:
+        cc = hipcc()          # raises when there is no compiler: a new geometry cannot be served on this machine
         if verbose:
-            print(f"[qinco_amd.build] compiling a kernel instance for ({Dp}, {Dep}, {Dhp}) [model ({D}, {De}, {Dh})]", file=sys.stderr)
-        _run([*cmd, "-MD", "-MF", str(so.with_suffix(".d"))])
-        so.with_suffix(".cmd").write_text(" ".join(cmd[1:]))
-    _lib.check(lib.qinco_load_instance(str(so).encode()))
-    return so
+            print(f"[qinco_amd.build] compiling {len(todo)} kernel instance(s) for ({Dp}, {Dep}, {Dhp}) [model ({D}, {De}, {Dh})]",
+                  file=sys.stderr)
+
+        def compile_one(job):
+            so, cmd = job
+            _run([cc, *cmd[1:], "-MD", "-MF", str(so.with_suffix(".d"))])
+            so.with_suffix(".cmd").write_text(" ".join(cmd[1:]))
+        with cf.ThreadPoolExecutor(max_workers=len(todo)) as ex:
+            list(ex.map(compile_one, todo))
+    for so, _, _ in jobs:                    # the encode instance first: the first entry of a shape is its production instance
+        _lib.check(lib.qinco_load_instance(str(so).encode()))
+    return jobs[0][0]
 
 
 if __name__ == "__main__":

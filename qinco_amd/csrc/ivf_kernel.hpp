@@ -12,6 +12,7 @@
 
 #include "aux_kernels.hpp"
 #include "mlp_args.hpp"
+#include "table_kernel.hpp"
 
 namespace qinco {
 
@@ -133,268 +134,6 @@ __global__ void ivf_finish_kernel(const unsigned long long* __restrict__ best, l
     const unsigned long long k = best[i];
     ids[i] = k == ~0ull ? 0 : (int)(k & 0xffffffffu);
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1+K2 on the matrix cores: the residual -> codebook table of dist_topk_kernel (aux_kernels.hpp) for K = 32*NKB
-// codewords, evaluated like the IVF table (a wave = 32 groups as B operands, codebook fragments as A operands), then the
-// T smallest per group, ascending.  r = x - xhat is formed on load (blocks are streamed, so any D fits), |r|^2 on the fly.
-// The 32 x K tile of a wave goes through a wave-private LDS table in two halves of 16 groups ([16][K + 4] floats): 66.5 KiB
-// per workgroup and <= 256 registers, so that TWO workgroups share a CU -- the table phase (matrix pipe) and the selection
-// phase (VALU / LDS / SALU latency chains) of a wave do not overlap with themselves, only with another wave's.
-// Selection: threshold-and-compact (aux_kernels.hpp, wave_select_smallest_multi), four groups side by side; T = 1 and
-// T > 64 take rounds of wave arg-min.
-// (history: VALU table 621 us per 65 536 groups -> MFMA table + T arg-min rounds 235 us -> this form, profiles/r02_*)
-// ---------------------------------------------------------------------------------------------
-template <int D, int NKB>
-__global__ void __launch_bounds__(256, 2)
-dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xhat, int F,
-                      const f32x4* __restrict__ cstream, const float* __restrict__ cnorm, long G, int T,
-                      int* __restrict__ ids_out, int gpw) {
-  // gpw = groups per wave (32, or 8 for small launches, which could not fill the chip with 32-group waves; lanes past gpw
-  // repeat the last group in the MFMA tile and are not selected)
-  constexpr int NDB = D / 32, K = NKB * 32, LDK = K + 4, SGP = 4;
-  __shared__ __attribute__((aligned(16))) float table[4 * 16 * LDK];
-  __shared__ unsigned long long surv_all[4 * SGP * SEL_SURV];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 31, half = lane >> 5;
-  const long g0 = ((long)blockIdx.x * 4 + wave) * gpw;
-  if (g0 >= G) return;  // wave-uniform; only wave-level ordering below
-  long g = g0 + (j < gpw ? j : gpw - 1);
-  if (g >= G) g = G - 1;
-  const float* xp = x + (g / F) * D + half * 4;
-  const float* hp = xhat ? xhat + g * D + half * 4 : nullptr;
-  const f32x4* wp = cstream + lane;
-  f32x16 acc[NKB];
-#pragma unroll
-  for (int cb = 0; cb < NKB; ++cb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
-  // Codebook fragments in the order they are used (feature block, q, codeword block) through a fenced register ring,
-  // the raw x / xhat rows of the next feature block fetched before the current block's MFMAs.
-  constexpr int NFR = NDB * 4 * NKB, P = 8;
-  auto frag_ofs = [](int i) { return (((i % NKB) * NDB + i / (4 * NKB)) * 4 + (i / NKB) % 4) * 64; };
-  f32x4 ring[P];
-#pragma unroll
-  for (int i = 0; i < P; ++i) ring[i] = wp[frag_ofs(i)];
-  f32x4 xr[4], hr[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    xr[q] = *reinterpret_cast<const f32x4*>(xp + 8 * q);
-    if (hp) hr[q] = *reinterpret_cast<const f32x4*>(hp + 8 * q);
-  }
-  float rn = 0.f;
-  static_assert((4 * NKB) % P == 0, "ring slots must not depend on the feature block");
-  constexpr int IB_UNROLL = NDB > 2 ? 1 : NDB;  // feature-block loop rolled: 255 registers, no spills (2 waves per SIMD); unrolled it spills and is slower
-#pragma unroll IB_UNROLL
-  for (int ib = 0; ib < NDB; ++ib) {
-    f32x16 rb;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 t = xr[q];
-      if (hp) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = __fsub_rn(t[e], hr[q][e]);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        rb[4 * q + e] = t[e];
-        rn = fmaf(t[e], t[e], rn);
-      }
-    }
-    if (ib + 1 < NDB) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        xr[q] = *reinterpret_cast<const f32x4*>(xp + (ib + 1) * 32 + 8 * q);
-        if (hp) hr[q] = *reinterpret_cast<const f32x4*>(hp + (ib + 1) * 32 + 8 * q);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int cb = 0; cb < NKB; ++cb) {
-        const int i = (ib * 4 + q) * NKB + cb;
-        const f32x4 w = ring[(q * NKB + cb) % P];
-        ring[(q * NKB + cb) % P] = wp[frag_ofs(i + P)];  // past the end: inside the 16-fragment padding of the stream
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], rb[4 * q + e], acc[cb], 0, 0, 0);
-      }
-  }
-  static_assert(NFR > 0, "");
-  rn += __shfl_xor(rn, 32);
-  // distances in place of the dot products: (|r|^2 + |c|^2) - 2 r.c  (the reference's association, utils.py:336-346)
-#pragma unroll
-  for (int cb = 0; cb < NKB; ++cb)
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + cb * 32 + 8 * gq + 4 * half);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[cb][4 * gq + e] = __fsub_rn(__fadd_rn(rn, cn[e]), __fmul_rn(2.f, acc[cb][4 * gq + e]));
-    }
-  float* mytab = table + wave * 16 * LDK;
-  unsigned long long* surv = surv_all + wave * SGP * SEL_SURV;
-  const int gend = (int)((G - g0) < gpw ? (G - g0) : gpw);
-  for (int h = 0; h < 2 && h * 16 < gend; ++h) {
-    // groups h*16 .. h*16+15 of the tile -> table rows 0..15
-    if ((j >> 4) == h) {
-      float* row = mytab + (j & 15) * LDK;
-#pragma unroll
-      for (int cb = 0; cb < NKB; ++cb)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const f32x4 d = {acc[cb][4 * gq], acc[cb][4 * gq + 1], acc[cb][4 * gq + 2], acc[cb][4 * gq + 3]};
-          *reinterpret_cast<f32x4*>(row + cb * 32 + 8 * gq + 4 * half) = d;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int nrow = gend - h * 16 < 16 ? gend - h * 16 : 16;
-    const long gbase = g0 + h * 16;
-    if (T > 1 && T <= 64) {
-      for (int r0 = 0; r0 < nrow; r0 += SGP) {
-        // (rows past nrow hold stale distances of this wave: selected and discarded)
-        int rank[SGP], index[SGP];
-        const unsigned ok = wave_select_smallest_multi<SGP, K / 64>(mytab + r0 * LDK, LDK, T, surv, lane, rank, index);
-#pragma unroll
-        for (int u = 0; u < SGP; ++u) {
-          const int r = r0 + u;
-          if (r >= nrow) break;
-          if ((ok >> u) & 1) {
-            if (rank[u] >= 0) ids_out[(gbase + r) * T + rank[u]] = index[u];
-            continue;
-          }
-          float* dg = mytab + r * LDK;   // massive exact ties: the arg-min rounds
-          for (int t = 0; t < T; ++t) {
-            float bv = __builtin_inff();
-            int bi = 0x7fffffff;
-#pragma unroll
-            for (int k = lane; k < K; k += 64) {
-              const float v = dg[k];
-              const bool take = v < bv;
-              bv = take ? v : bv;
-              bi = take ? k : bi;
-            }
-            wave_argmin(bv, bi);
-            if (bi == 0x7fffffff) bi = 0;
-            if (lane == 0) ids_out[(gbase + r) * T + t] = bi;
-            if ((bi & 63) == lane) dg[bi] = __builtin_inff();
-            __builtin_amdgcn_wave_barrier();
-          }
-        }
-      }
-    } else {
-      // T == 1 (arg-min: step 0 of a greedy search) or T > 64: rounds of wave arg-min.  The rounds of one group are a chain
-      // of dependent cross-lane shuffles (latency-bound), so GP groups are reduced side by side.
-      constexpr int GP = 8;
-      for (int r0 = 0; r0 < nrow; r0 += GP) {
-        for (int t = 0; t < T; ++t) {
-          float bv[GP];
-          int bi[GP];
-#pragma unroll
-          for (int u = 0; u < GP; ++u) {
-            const float* dg = mytab + (r0 + u < 16 ? r0 + u : 15) * LDK;
-            bv[u] = __builtin_inff();
-            bi[u] = 0x7fffffff;
-#pragma unroll
-            for (int k = lane; k < K; k += 64) {  // k ascends: strict < keeps the lowest index
-              const float v = dg[k];
-              const bool take = v < bv[u];
-              bv[u] = take ? v : bv[u];
-              bi[u] = take ? k : bi[u];
-            }
-          }
-          wave_argmin_u<GP>(bv, bi);  // GP interleaved integer-min chains: no branch, no SGPR round trip
-#pragma unroll
-          for (int u = 0; u < GP; ++u) {
-            if (r0 + u < nrow) {
-              int b = bi[u] == 0x7fffffff ? 0 : bi[u];
-              if (lane == 0) ids_out[(gbase + r0 + u) * T + t] = b;
-              if ((b & 63) == lane) mytab[(r0 + u) * LDK + b] = __builtin_inff();
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();   // the next half overwrites the rows
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same table + top-T for SMALL launches (G <= 16 384 groups, e.g. the reference's default batch of 1024 vectors with 8
-// beams): dist_topk_mfma_kernel fills the chip only with 8 groups per wave, and each of those waves still pays a full 32-column
-// table (32.8 k MFMA cycles at D = 128) before it selects anything: 27 us per step at 8192 groups, 18 % of a split-form
-// qinco2-S step.  Here the four waves of a workgroup share 32 groups: every wave computes a quarter of the codewords for all 32
-// (8.2 k MFMA cycles), the distances meet in one LDS table, and after a barrier each wave selects 8 of the groups.
-// ---------------------------------------------------------------------------------------------
-template <int D, int NKB>
-__global__ void __launch_bounds__(256)
-dist_topk_mfma_coop_kernel(const float* __restrict__ x, const float* __restrict__ xhat, int F,
-                           const f32x4* __restrict__ cstream, const float* __restrict__ cnorm, long G, int T,
-                           int* __restrict__ ids_out) {
-  constexpr int NDB = D / 32, K = NKB * 32, LDK = K + 4, SGP = 4, CPW = NKB / 4;   // codeword blocks per wave
-  static_assert(NKB % 4 == 0, "the codeword blocks are split over four waves");
-  __shared__ __attribute__((aligned(16))) float table[32 * LDK];
-  __shared__ unsigned long long surv_all[4 * SGP * SEL_SURV];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = lane & 31, half = lane >> 5;
-  const long g0 = (long)blockIdx.x * 32;
-  long g = g0 + j;
-  if (g >= G) g = G - 1;
-  const float* xp = x + (g / F) * D + half * 4;
-  const float* hp = xhat ? xhat + g * D + half * 4 : nullptr;
-  // fragment (cb, ib, q) of the stream = 64 lanes x float4 at ((cb * NDB + ib) * 4 + q) * 64
-  const f32x4* wp = cstream + (long)(wave * CPW) * NDB * 4 * 64 + lane;
-  f32x16 acc[CPW];
-#pragma unroll
-  for (int c = 0; c < CPW; ++c)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
-  float rn = 0.f;
-#pragma unroll
-  for (int ib = 0; ib < NDB; ++ib) {
-    f32x16 rb;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 t = *reinterpret_cast<const f32x4*>(xp + ib * 32 + 8 * q);
-      if (hp) {
-        const f32x4 hq = *reinterpret_cast<const f32x4*>(hp + ib * 32 + 8 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = __fsub_rn(t[e], hq[e]);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        rb[4 * q + e] = t[e];
-        rn = fmaf(t[e], t[e], rn);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < CPW; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 w = wp[((c * NDB + ib) * 4 + q) * 64];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], rb[4 * q + e], acc[c], 0, 0, 0);
-      }
-  }
-  rn += __shfl_xor(rn, 32);
-  // distances (|r|^2 + |c|^2) - 2 r.c (the reference's association, utils.py:336-346) into row j of the shared table
-#pragma unroll
-  for (int c = 0; c < CPW; ++c) {
-    const int cb = wave * CPW + c;
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + cb * 32 + 8 * gq + 4 * half);
-      f32x4 d;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d[e] = __fsub_rn(__fadd_rn(rn, cn[e]), __fmul_rn(2.f, acc[c][4 * gq + e]));
-      *reinterpret_cast<f32x4*>(table + j * LDK + cb * 32 + 8 * gq + 4 * half) = d;
-    }
-  }
-  __syncthreads();
-  coop_select_rows<K, LDK, SGP>(table, surv_all + wave * SGP * SEL_SURV, lane, wave, g0, G, T, ids_out);
 }
 
 }  // namespace qinco

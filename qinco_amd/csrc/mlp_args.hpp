@@ -86,6 +86,20 @@ struct XprojArgs {
   int T;                  // candidates to keep per group
   int* ids_out;           // (G, T)
 };
+// The pre-selection table + top-T alone (table_kernel.hpp): step 0, and encode steps whose launch is too large for the fused
+// small-launch kernel.  Compiled-in for the reference's dataset dimensions; a module built on demand brings its own for its D.
+struct TableArgs {
+  const float* x;         // (G / F, D) normalised targets
+  const float* xhat;      // (G, D) or nullptr (step 0: r = x)
+  int F;
+  const f32x4* cstream;   // codebook (K = 256) as MFMA fragments (cb, ib, q)
+  const float* cnorm;     // (K) |c_k|^2
+  long G;
+  int T;
+  int* ids_out;           // (G, T)
+  int coop;               // 1: the cooperative small-launch kernel
+};
+
 // 1 if the instance's xproj launcher serves XprojArgs::cstream (the fused small-launch kernel exists for the shape)
 constexpr bool presel_coop_ok(int DE, int DH, int var) {
   return (DE / 32) % 4 == 0 && (DH / 32) % 4 == 0 && DE <= 384 && (var & 16) && !(var & 128) && !(var & 512);

@@ -37,7 +37,7 @@ using namespace qinco;
 namespace qinco {
 static const MlpInstance g_instances[] = {
 #define QINCO_SHAPE(d, de, dh, p, var) \
-  {d, de, dh, p, var, &qinco_mlp_launch_##d##_##de##_##dh##_##p##_##var, &qinco_xproj_launch_##d##_##de##_##dh##_##p##_##var},
+  {d, de, dh, p, var, &qinco_mlp_launch_##d##_##de##_##dh##_##p##_##var, &qinco_xproj_launch_##d##_##de##_##dh##_##p##_##var, nullptr},
 #include "shapes.def"
 #undef QINCO_SHAPE
 };
@@ -179,9 +179,11 @@ struct qinco_handle_s {
 #endif
 };
 
-// the MFMA table kernel is instantiated for K = 256 and the D of the MLP/IVF instances
-static bool mfma_table_ok(const qinco_desc& d) {
-  return d.K == 256 && (d.D == 32 || d.D == 96 || d.D == 128 || d.D == 256 || d.D == 768);
+// the MFMA table kernel is instantiated here for K = 256 and the D of the compiled-in MLP / IVF instances; a kernel-instance module
+// built on demand brings one for its own D (MlpInstance::table)
+static bool builtin_table_dim(int D) { return D == 32 || D == 96 || D == 128 || D == 256 || D == 768; }
+static bool mfma_table_ok(const qinco_desc& d, const MlpInstance* inst) {
+  return d.K == 256 && (builtin_table_dim(d.D) || (inst && inst->table));
 }
 
 // candidates pre-selected at step m (QincoSubstep._n_codes, qinco_base.py:108-112)
@@ -634,7 +636,7 @@ extern "C" int qinco_load_instance(const char* path) {
                                    "with -DQINCO_INSTANCE_MODULE?)", path);
   }
   int32_t v[6] = {0, 0, 0, 0, 0, 0};
-  void* fns[2] = {nullptr, nullptr};
+  void* fns[3] = {nullptr, nullptr, nullptr};
   const int abi = info(v, fns), want_abi = (int)((sizeof(MlpArgs) << 16) | sizeof(XprojArgs));
   if (abi != want_abi || !fns[0] || !fns[1]) {
     dlclose(so);
@@ -644,7 +646,7 @@ extern "C" int qinco_load_instance(const char* path) {
   for (const MlpInstance& i : g_loaded)
     if (i.D == v[0] && i.De == v[1] && i.Dh == v[2] && i.P == v[3] && i.var == v[4]) return QINCO_OK;   // already there
   g_loaded.push_back(MlpInstance{v[0], v[1], v[2], v[3], v[4], reinterpret_cast<mlp_launch_fn>(fns[0]),
-                                 reinterpret_cast<xproj_launch_fn>(fns[1])});
+                                 reinterpret_cast<xproj_launch_fn>(fns[1]), reinterpret_cast<table_launch_fn>(fns[2])});
   return QINCO_OK;
 }
 
@@ -906,7 +908,7 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
       if (d.ivf_K > 0) {
         if ((rc = upload_fragments(h, w->codebook[0], d.ivf_K, d.D, &h->ivf_stream))) return bail(rc);
         if (!(create_flags & QINCO_CREATE_IVF_FP32) && (rc = build_ivf_f16(h, w->codebook[0]))) return bail(rc);
-      } else if (mfma_table_ok(d)) {
+      } else if (mfma_table_ok(d, h->inst)) {
         if ((rc = upload_fragments(h, w->codebook[0], d.K, d.D, &h->cb_stream[0]))) return bail(rc);
       }
       continue;
@@ -914,7 +916,7 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
     if (d.A > 0) {
       if (!w->sub_codebook[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: sub_codebook[%d] is null", m));
       if ((rc = upload_with_norms(h, w->sub_codebook[m], d.K, d.D, &h->sub_codebook[m], &h->sub_cnorm[m]))) return bail(rc);
-      if (mfma_table_ok(d) && (rc = upload_fragments(h, w->sub_codebook[m], d.K, d.D, &h->sub_stream[m]))) return bail(rc);
+      if (mfma_table_ok(d, h->inst) && (rc = upload_fragments(h, w->sub_codebook[m], d.K, d.D, &h->sub_stream[m]))) return bail(rc);
     }
     // packed stream, in the order mlp_kernel consumes it
     const StreamDims& sd = h->sd;
@@ -1153,7 +1155,7 @@ struct PreselJob {   // the step's pre-selection, when it rides in the xproj lau
 // over four waves, a launch small enough for the cooperative form
 static bool presel_fused(const qinco_handle_s* h, long G) {
   return h->inst && h->table_coop && !h->table_valu && !h->split16 && h->fold && G <= h->table_coop_max && h->d.K == 256 &&
-         mfma_table_ok(h->d) && presel_coop_ok(h->d.De, h->d.Dh, h->inst->var) && !h->no_presel_fusion;
+         mfma_table_ok(h->d, h->inst) && presel_coop_ok(h->d.De, h->d.Dh, h->inst->var) && !h->no_presel_fusion;
 }
 
 static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool decode = false, const PreselJob* pj = nullptr) {
@@ -1220,31 +1222,21 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
   return 0;
 }
 
-template <int D>
-static void launch_table_inst(const qinco_handle_s* h, const float* x, const float* xhat, int F, const f32x4* cs, const float* cn, long G,
-                              int T, int* ids, hipStream_t st) {
-  if (G <= h->table_coop_max && h->table_coop) {   // small launches: the four waves of a workgroup share 32 groups (ivf_kernel.hpp)
-    hipLaunchKernelGGL((dist_topk_mfma_coop_kernel<D, 8>), dim3((unsigned)((G + 31) / 32)), dim3(256), 0, st, x, xhat, F, cs, cn, G, T,
-                       ids);
-    return;
-  }
-  const int gpw = G <= 16384 ? 8 : 32;  // (without the cooperative kernel: small launches with 8 groups per wave, the round-2 form)
-  hipLaunchKernelGGL((dist_topk_mfma_kernel<D, 8>), dim3((unsigned)((G + 4 * gpw - 1) / (4 * gpw))), dim3(256), 0, st, x, xhat,
-                     F, cs, cn, G, T, ids, gpw);
-}
-
 static int launch_dist_topk(qinco_handle_s* h, const float* x, const float* xhat, int F, const float* cb,
                             const f32x4* cstream, const float* cn, long G, int T, int* ids, hipStream_t st) {
   const qinco_desc& d = h->d;
   if (cstream && !h->table_valu) {
-    switch (d.D) {
-      case 32: launch_table_inst<32>(h, x, xhat, F, cstream, cn, G, T, ids, st); break;
-      case 96: launch_table_inst<96>(h, x, xhat, F, cstream, cn, G, T, ids, st); break;
-      case 128: launch_table_inst<128>(h, x, xhat, F, cstream, cn, G, T, ids, st); break;
-      case 256: launch_table_inst<256>(h, x, xhat, F, cstream, cn, G, T, ids, st); break;
-      default: launch_table_inst<768>(h, x, xhat, F, cstream, cn, G, T, ids, st); break;
+    TableArgs ta{x, xhat, F, cstream, cn, G, T, ids, (G <= h->table_coop_max && h->table_coop) ? 1 : 0};
+    hipError_t e;
+    switch (builtin_table_dim(d.D) ? d.D : 0) {
+      case 32: e = launch_table_kernels<32>(ta, st); break;
+      case 96: e = launch_table_kernels<96>(ta, st); break;
+      case 128: e = launch_table_kernels<128>(ta, st); break;
+      case 256: e = launch_table_kernels<256>(ta, st); break;
+      case 768: e = launch_table_kernels<768>(ta, st); break;
+      default: e = h->inst->table(&ta, st); break;   // (cstream is only packed when mfma_table_ok: the module has a launcher)
     }
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(e);
     return 0;
   }
   size_t lds = ((size_t)DT_TG * d.D + 256 * DT_CP + (size_t)DT_TG * d.K + DT_TG) * sizeof(float);
@@ -1662,7 +1654,7 @@ extern "C" int qinco_describe(qinco_handle h, char* buf, int32_t cap) {
   const MlpInstance* i = h->inst;
   const int n = snprintf(tmp, sizeof(tmp), "model=%dx%dx%d mlp=%dx%dx%d P=%d var=%d decode_var=%d form=%s tile=%d table=%s ivf=%s", h->user.D,
                          h->user.De, h->user.Dh, h->d.D, h->d.De, h->d.Dh, i ? i->P : 0, i ? i->var : -1, h->dec_inst ? h->dec_inst->var : -1, h->split16 ? "split-fp16" : "fp32",
-                         (i && (i->var & 128)) ? 16 : 32, (mfma_table_ok(h->d) && !h->table_valu) ? "mfma" : "valu",
+                         (i && (i->var & 128)) ? 16 : 32, (mfma_table_ok(h->d, h->inst) && !h->table_valu) ? "mfma" : "valu",
                          h->d.ivf_K == 0 ? "none" : (h->ivf_f16 ? "fp16-filter+fp32" : "fp32"));
   if (buf && cap > 0) {
     strncpy(buf, tmp, (size_t)cap - 1);

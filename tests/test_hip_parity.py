@@ -359,7 +359,7 @@ def test_input_formats(engines):
     dict(D=100, de=None, dh=200, L=2, A=0, B=1, qinco1_mode=True),     # QINCo1-style, De = D = 100, Dh 200 -> 224
     dict(D=100, de=128, dh=256, L=2, A=8, B=4),                        # padding must not turn the projections into identities
     dict(D=64, de=96, dh=160, L=2, A=8, B=2),                          # multiples of 32 that shapes.def does not list
-    dict(D=200, de=200, dh=300, L=2, A=16, B=4),                       # De == D given explicitly; VALU pre-selection table
+    dict(D=200, de=200, dh=300, L=2, A=16, B=4),                       # De == D given explicitly; D padded to 224: the module's own MFMA table
 ], ids=lambda kw: f"D{kw['D']}_de{kw['de']}_dh{kw['dh']}")
 def test_arbitrary_geometry_builds_an_instance_on_demand(kw):
     """The reference builds any (D, de, dh, L) (qinco_base.py:229-260).  Geometries outside csrc/shapes.def: QincoEngine pads
@@ -385,6 +385,11 @@ def test_arbitrary_geometry_builds_an_instance_on_demand(kw):
     assert abs(eng.flops_per_vector("encode") - cfg.encode_flops_per_vector()) < 1e-6 * cfg.encode_flops_per_vector()
     print(f"{kw}: {nbad} rows on ties")
     eng.close()
+    if cfg.D == 200:   # the VALU pre-selection table at a padded D of 224 needs > 64 KiB of dynamic LDS: keep that path alive too
+        ev = QincoEngine(cfg, sd, max_batch=256, diagnostics={"table_valu": True})
+        assert "table=valu" in ev.describe()
+        assert_only_near_ties(oracle, x, ev.encode(x), want, NEAR_TIE, "VALU table")
+        ev.close()
 
 
 @pytest.mark.parametrize("model,D,B", [("qinco2-S", 128, 8), ("qinco2-L", 128, 8), ("qinco2-S", 768, 4), ("qinco2-S", 96, 8),

@@ -360,7 +360,8 @@ def test_input_formats(engines):
     dict(D=100, de=128, dh=256, L=2, A=8, B=4),                        # padding must not turn the projections into identities
     dict(D=64, de=96, dh=160, L=2, A=8, B=2),                          # multiples of 32 that shapes.def does not list
     dict(D=200, de=200, dh=300, L=2, A=16, B=4),                       # De == D given explicitly; D padded to 224: the module's own MFMA table
-], ids=lambda kw: f"D{kw['D']}_de{kw['de']}_dh{kw['dh']}")
+    dict(D=100, de=None, dh=200, L=2, A=8, B=4, ivf_K=2048),           # an IVF model at a padded dimension (centroids padded too)
+], ids=lambda kw: f"D{kw['D']}_de{kw['de']}_dh{kw['dh']}" + ("_ivf" if kw.get("ivf_K") else ""))
 def test_arbitrary_geometry_builds_an_instance_on_demand(kw):
     """The reference builds any (D, de, dh, L) (qinco_base.py:229-260).  Geometries outside csrc/shapes.def: QincoEngine pads
     to 32-feature blocks and compiles / loads one kernel instance on demand (qinco_amd.build.ensure_instance); results against
@@ -374,7 +375,7 @@ def test_arbitrary_geometry_builds_an_instance_on_demand(kw):
     oracle = make_oracle(cfg, sd)
     want = oracle(x, step="encode").T
     got, xhat = eng.encode(x, return_xhat=True)
-    assert got.shape == (300, cfg.M) and xhat.shape == (300, cfg.D)
+    assert got.shape == (300, cfg.M_total) and xhat.shape == (300, cfg.D)
     nbad = assert_only_near_ties(oracle, x, got, want, NEAR_TIE, str(kw))
     ok = (got == want).all(axis=1)
     ref = oracle(want.T, step="decode")

@@ -340,7 +340,7 @@ def main():
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs a GPU (qinco_amd has no CPU path)")
-    if args.backend == "nccl" and world > ndev:
+    if args.backend == "nccl" and world > ndev and not os.environ.get("QINCO_BENCH_NCCL_SHARED_GPU"):   # (test hook: let RCCL refuse it)
         raise SystemExit(f"{world} ranks but only {ndev} GPU(s): RCCL needs one GPU per rank (--backend gloo lets ranks share one)")
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)

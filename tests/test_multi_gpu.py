@@ -169,6 +169,27 @@ def test_bench_fails_soft_when_rccl_is_unavailable(mode):
     assert not mg["gather_ok_on_all_ranks"] and all(v > 0 for v in mg["per_rank_encode_vectors_per_s"])
 
 
+def test_bench_survives_a_real_rccl_refusal():
+    """The RCCL code path itself (communicator creation on a `nccl` sub-group next to the gloo control plane), on hardware: two
+    ranks on ONE GPU is something RCCL refuses (or never completes) -- the bench must notice, fall back to part files and still
+    print its line.  On a box with >= 2 GPUs the same command simply succeeds over RCCL."""
+    import os
+    import torch
+    os.environ["QINCO_BENCH_NCCL_SHARED_GPU"] = "1"
+    try:
+        rec = _bench("--gpus", "2", "--backend", "nccl", "--workload", "C1", "--batch", "256", "--steps", "1", "--warmup", "0",
+                     "--rccl-timeout", "60")
+    finally:
+        del os.environ["QINCO_BENCH_NCCL_SHARED_GPU"]
+    mg = rec["multi_gpu"]
+    print(mg["gather"], "|", mg["rccl_note"])
+    assert rec["value"] > 0 and all(v > 0 for v in mg["per_rank_encode_vectors_per_s"])
+    if torch.cuda.device_count() >= 2:
+        assert mg["gather"] == "rccl" and mg["gather_ok_on_all_ranks"]
+    else:
+        assert mg["gather"].startswith("failed:") and mg["rccl_note"] and not mg["gather_ok_on_all_ranks"]
+
+
 def test_bench_driver_line_carries_the_metric_grid():
     """The default legs of the driver's N = 1 line (BASELINE.json metric: beam in {1, 8} over its configs): c1 with the
     oracle code-identity count and its CPU sample, c3, c4, and the bvecs -> encode_database leg (here on a small file)."""

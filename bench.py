@@ -497,7 +497,8 @@ def main():
         rf["traffic"] = bpr * rows_per_launch if bpr else None
         rf["traffic_unit"] = f"bytes per launch (L2<->fabric, PMC pass in profiles/{bpr_src})" if bpr else None
         out = {
-            "metric": "encode vectors/sec (BigANN-shaped d=128 8x8, beam=%d)" % cfg.B,
+            "metric": ("encode vectors/sec (BigANN-shaped d=128 8x8, beam=%d)" % cfg.B) if args.workload in ("C1", "C2") else
+                      ("encode vectors/sec (d=%d %dx8, beam=%d)" % (cfg.D, cfg.M, cfg.B)),
             "value": value, "unit": "vectors/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3 if K else 0.0, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32" if not args.split_f16 else "f32 operands as fp16 hi+lo on the fp16 MFMA, fp32 accumulate (--split-f16)",

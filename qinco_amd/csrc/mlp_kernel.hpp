@@ -111,7 +111,9 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   constexpr bool LDSR = (VAR & 4) != 0;
   constexpr bool PINNED = (VAR & 8) != 0;
   constexpr bool SHR = (VAR & 64) != 0;
-  static_assert((VAR & ~(4 | 8 | 16 | 32 | 64 | 256)) == 0, "unknown VAR bits");
+  constexpr bool G8 = (VAR & 1024) != 0;   // shared ring with a barrier / refill every 8 fragments instead of every 4 (A/B variant)
+  static_assert((VAR & ~(4 | 8 | 16 | 32 | 64 | 256 | 1024)) == 0, "unknown VAR bits");
+  static_assert(!G8 || (SHR && P % 24 == 0 && P / 4 >= 7), "G8 is a form of the shared ring");
   static_assert(!OCC2 || (VAR & 8), "OCC2 is a form of the pinned plan");
   static_assert(!SHR || (LDSR && P % 12 == 0 && P / 4 >= 5), "shared ring: P multiple of 12 (3 register sets, 4 issuers)");
   static_assert(!LDSR || SHR || (P % 3 == 0 && P >= 6 && P <= 39), "per-wave LDS rings: 4 x P KiB must fit 160 KiB");
@@ -172,7 +174,14 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
     asm volatile("" ::: "memory");
   };
-  if constexpr (SHR) {
+  if constexpr (SHR && G8) {
+    // fragments 0 .. P-9 are issued (P/4 - 2 per wave); "<= P/4 - 3 outstanding" = every wave's first one landed
+    static_for<P / 4 - 2>([&]<int i>() QINCO_LAMBDA { dma.template operator()<4 * i>(); });
+    wait_vm.template operator()<P / 4 - 3>();
+    __builtin_amdgcn_s_barrier();
+    ring[0] = myring[lane];
+    ring[1] = myring[64 + lane];
+  } else if constexpr (SHR) {
     // fragments 0 .. P-5 are issued (P/4 - 1 per wave); "<= P/4 - 2 outstanding" = every wave's first one landed
     static_for<P / 4 - 1>([&]<int i>() QINCO_LAMBDA { dma.template operator()<4 * i>(); });
     wait_vm.template operator()<P / 4 - 2>();
@@ -191,7 +200,20 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   }
   stamp(1);   // ring prologue done (first fragments landed, first barrier passed)
   auto take = [&]<int T>() QINCO_LAMBDA -> f32x4 {
-    if constexpr (SHR) {
+    if constexpr (SHR && G8) {
+      // Groups of 8.  Before fragment T = 8g every wave has issued 2g + P/4 - 2 DMAs; "<= P/4 - 5 outstanding" = its first
+      // 2g + 3 landed, so past the barrier fragments <= 8g + 11 are in LDS: covers the reads (<= 8g + 9) of this group.  The
+      // two refills overwrite fragments 8g - 8 .. 8g - 1, which every wave consumed before this barrier.
+      if constexpr ((T & 7) == 0) {
+        wait_vm.template operator()<P / 4 - 5>();
+        __builtin_amdgcn_s_barrier();
+        dma.template operator()<T + P - 8>();
+        dma.template operator()<T + P - 4>();
+      }
+      ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
+      asm volatile("" ::: "memory");
+      return ring[T % 3];
+    } else if constexpr (SHR) {
       // Before fragment T = 4g every wave has issued g + P/4 - 1 DMAs; "<= P/4 - 3 outstanding" = its first g + 2
       // landed, so past the barrier fragments <= 4g + 7 are in LDS: covers the reads (<= 4g + 5) of this group.
       // The refill overwrites fragments 4g - 4 .. 4g - 1, which every wave consumed before this barrier.
@@ -230,7 +252,7 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
     // pin makes the last fragment ahead of the barrier a register value at this point of the program; the ring reads are
     // issued in program order (memory fences in take) and LDS returns a wave's reads in order, so every earlier fragment has
     // arrived too; asm volatile does not cross the barrier's fences.  Costs 0.8 % at C2, gains 1.2 % at qinco2-S.
-    if constexpr (SHR && (T & 3) == 3) pin4_v(w);
+    if constexpr (SHR && (T & (G8 ? 7 : 3)) == (G8 ? 7 : 3)) pin4_v(w);
     static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA(w[e], b[4 * q + e], acc); });
     extra();
   };
@@ -280,7 +302,7 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
       static_for<4>([&]<int q>() QINCO_LAMBDA {
         f32x4 w = take.template operator()<ob * 4 + q>();
-        if constexpr (SHR && ((ob * 4 + q) & 3) == 3) pin4_v(w);   // (see fragmm)
+        if constexpr (SHR && ((ob * 4 + q) & (G8 ? 7 : 3)) == (G8 ? 7 : 3)) pin4_v(w);   // (see fragmm)
         static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob][4 * q + e] = w[e]; });
       });
     });

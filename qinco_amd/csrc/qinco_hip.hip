@@ -856,6 +856,8 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   h->sd = stream_dims(d.D, d.De, d.Dh, kRing, h->fold, h->fold2, tile16 ? 16 : 32);
   if (h->fold && !(create_flags & QINCO_CREATE_DECODE_FOLDED)) {
     const MlpInstance* di = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~(16 | 32));
+    if (!di || (di->var & (16 | 32)))   // (the un-folded twins are compiled with ring groups of 4)
+      di = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~(16 | 32 | 1024));
     if (di && !(di->var & (16 | 32 | 128)) && di->P == fn->P) {
       h->dec_inst = di;
       h->dec_sd = stream_dims(d.D, d.De, d.Dh, di->P, false, false, 32);

@@ -27,14 +27,18 @@ namespace qinco {
 // (The bisection switches that isolated the co-residency failure of this kernel in round 2 -- profiles/r02_mlp16_bisect.log,
 // DESIGN.md 3.1b -- are gone from this header; the commit history has them.)
 
-template <int D, int DE, int DH, int P>
+// GK = DMAs per wave per ring boundary: 1 = a barrier / refill every 4 fragments (round 2), 2 = every 8 (VAR bit 1024; see
+// mlp_kernel.hpp G8 -- a fragment feeds only 128 matrix-pipe cycles here, so the boundary is twice as expensive per FLOP).
+template <int D, int DE, int DH, int P, int GK = 1>
 __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
+  constexpr int GM = 4 * GK - 1;   // fragment-index mask of a ring group
+  static_assert(GK == 1 || GK == 2, "ring groups of 4 or 8 fragments");
+  static_assert(P % (12 * GK) == 0 && P / 4 >= 2 * GK + 3, "ring depth against the group size");
   constexpr StreamDims SL = stream_dims(D, DE, DH, P, false, false, 16);
   constexpr int NDB = SL.NDB, NEB = SL.NEB, NHB = SL.NHB;  // 16-feature blocks
   constexpr bool PROJ = SL.PROJ;
   constexpr int NYB0 = NHB > NEB ? NHB : NEB;
   constexpr int NYB = (PROJ && NDB > NYB0) ? NDB : NYB0;
-  static_assert(P % 12 == 0 && P / 4 >= 5, "shared ring: P multiple of 12");
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -65,16 +69,17 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
     asm volatile("" ::: "memory");
   };
-  static_for<P / 4 - 1>([&]<int i>() QINCO_LAMBDA { dma.template operator()<4 * i>(); });
-  wait_vm.template operator()<P / 4 - 2>();
+  // (P/4 - GK DMAs per wave in the prologue; "<= P/4 - GK - 1 outstanding" = every wave's first one landed)
+  static_for<P / 4 - GK>([&]<int i>() QINCO_LAMBDA { dma.template operator()<4 * i>(); });
+  wait_vm.template operator()<P / 4 - GK - 1>();
   __builtin_amdgcn_s_barrier();
   ring[0] = myring[lane];
   ring[1] = myring[64 + lane];
   auto take = [&]<int T>() QINCO_LAMBDA -> f32x4 {
-    if constexpr ((T & 3) == 0) {
-      wait_vm.template operator()<P / 4 - 3>();
+    if constexpr ((T & GM) == 0) {   // before fragment T = 4 GK g a wave has issued P/4 - GK + GK g DMAs and needs GK g + GK + 1 landed
+      wait_vm.template operator()<P / 4 - 2 * GK - 1>();
       __builtin_amdgcn_s_barrier();
-      dma.template operator()<T + P - 4>();
+      static_for<GK>([&]<int k>() QINCO_LAMBDA { dma.template operator()<T + P - 4 * GK + 4 * k>(); });
     }
     ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
     asm volatile("" ::: "memory");   // the ring reads keep their program order (see fragmm)
@@ -95,7 +100,7 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
     // The ring reads keep their program order (memory fence in take), LDS returns a wave's reads in order, so pinning the LAST
     // fragment in front of each barrier covers the earlier ones; a section whose live fragments do not end on such a fragment
     // finishes with lgkmcnt(0) (section_done).  (Pinning every fragment, the first form of the fix, cost 3.6 %.)
-    if constexpr ((T & 3) == 3) pin4_v(w);
+    if constexpr ((T & GM) == GM) pin4_v(w);
     static_for<4>([&]<int e>() QINCO_LAMBDA { acc = QINCO_MFMA16(w[e], b[e], acc); });
   };
   auto section_done = [&]() QINCO_LAMBDA {   // every LDS read of this wave has completed (once per section)

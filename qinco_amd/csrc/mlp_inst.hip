@@ -39,7 +39,7 @@ hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::Mlp
 #elif (QVAR & 128)  // 16-row tile form (mlp16_kernel.hpp)
   const long tiles = (a->R + 15) / 16;
   const unsigned grid = (unsigned)((tiles + 3) / 4);
-  hipLaunchKernelGGL((qinco::mlp16_kernel<QD, QDE, QDH, QP>), dim3(grid), dim3(256), kExclusiveLds, stream, *a);
+  hipLaunchKernelGGL((qinco::mlp16_kernel<QD, QDE, QDH, QP, (QVAR & 1024) ? 2 : 1>), dim3(grid), dim3(256), kExclusiveLds, stream, *a);
 #else
   const long tiles = (a->R + 31) / 32;
   const unsigned grid = (unsigned)((tiles + 3) / 4);

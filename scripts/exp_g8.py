@@ -9,9 +9,9 @@ from qinco_amd.config import BASELINE_CONFIGS, preset
 EXTRA = {"L_d96": preset("qinco2-L", D=96, M=8, B=8), "L_d256": preset("qinco2-L", D=256, M=8, B=8), "Q1_d256": preset("qinco1", D=256, M=8),
          "M": BASELINE_CONFIGS["M"]}
 WL = [("C2", (48, 1148)), ("S", (48, 1404)), ("C1", (48, 1404))] if len(sys.argv) < 2 else \
-    [(w, (48, 1220) if w == "Q1_768" else (48, 1148)) for w in sys.argv[1:]]
+    [(w, (48, 2244) if w == "Q1_768_16" else (48, 1220) if w == "Q1_768" else (48, 1148)) for w in sys.argv[1:]]
 for wl, var in WL:
-    cfg = EXTRA.get(wl) or BASELINE_CONFIGS[wl]
+    cfg = EXTRA.get(wl) or BASELINE_CONFIGS[wl.replace("_16", "")]
     sd = synth_state_dict(cfg, 1236)
     ref = None
     for v in (None, var, None, var):
@@ -19,7 +19,7 @@ for wl, var in WL:
         x = torch.from_numpy(synth_vectors(cfg, sd, 16384, seed=1)).cuda()
         c, h = eng.encode(x, return_xhat=True); torch.cuda.synchronize()
         eng.profile_enable(True); eng.profile_read()
-        reps = 2 if wl == "Q1_768" else 4 if wl != "S" else 12
+        reps = 2 if wl.startswith("Q1_768") else 4 if wl != "S" else 12
         t0 = time.perf_counter()
         for _ in range(reps): eng.encode(x, code_dtype=np.uint8)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0

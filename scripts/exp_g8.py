@@ -8,10 +8,15 @@ from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
 from qinco_amd.config import BASELINE_CONFIGS, preset
 EXTRA = {"L_d96": preset("qinco2-L", D=96, M=8, B=8), "L_d256": preset("qinco2-L", D=256, M=8, B=8), "Q1_d256": preset("qinco1", D=256, M=8),
          "M": BASELINE_CONFIGS["M"]}
-WL = [("C2", (48, 1148)), ("S", (48, 1404)), ("C1", (48, 1404))] if len(sys.argv) < 2 else \
-    [(w, (48, 2244) if w == "Q1_768_16" else (48, 1220) if w == "Q1_768" else (48, 1148)) for w in sys.argv[1:]]
+def parse(w):   # "C2" (its ring-groups-of-8 variant) or "C2@96,1148" (an explicit P,VAR)
+    if "@" in w:
+        return w.split("@")[0], tuple(int(v) for v in w.split("@")[1].split(","))
+    return w, (48, 1220) if w == "Q1_768" else (48, 1148)
+
+
+WL = [("C2", (48, 1148)), ("S", (48, 1404)), ("C1", (48, 1404))] if len(sys.argv) < 2 else [parse(w) for w in sys.argv[1:]]
 for wl, var in WL:
-    cfg = EXTRA.get(wl) or BASELINE_CONFIGS[wl.replace("_16", "")]
+    cfg = EXTRA.get(wl) or BASELINE_CONFIGS[wl]
     sd = synth_state_dict(cfg, 1236)
     ref = None
     for v in (None, var, None, var):

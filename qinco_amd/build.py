@@ -157,9 +157,9 @@ def ensure_instance(D: int, De: int, Dh: int, verbose: bool = False) -> Path | N
     except OSError:       # a read-only installation: the user's cache directory instead of the package directory
         inst_dir = Path(os.environ.get("XDG_CACHE_HOME", Path.home() / ".cache")) / "qinco_amd" / "instances"
         inst_dir.mkdir(parents=True, exist_ok=True)
-    # the encode instance, and -- for the folded 32-row forms -- the un-folded twin decode runs on (one row per group shares
-    # nothing, so the folded head is pure overhead there: DESIGN.md 3.1); compiled side by side
-    variants = [var] + ([var & ~(16 | 32)] if (var & 16) and not (var & 128) else [])
+    # the encode instance, and -- for the two-workgroups-per-CU forms -- the un-folded twin decode runs on (DESIGN.md 3.1:
+    # faster there, slower on the wide shapes); compiled side by side
+    variants = [var] + ([var & ~(16 | 32)] if (var & 16) and (var & 256) else [])   # (the twin pays on the OCC2 shapes only)
     jobs = []
     for v in variants:
         so = inst_dir / f"inst_{Dp}_{Dep}_{Dhp}_{P}_{v}.so"

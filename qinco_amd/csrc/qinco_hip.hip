@@ -854,10 +854,12 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   h->split16 = fn && (fn->var & 512);
   const bool tile16 = fn && (fn->var & 128);
   h->sd = stream_dims(d.D, d.De, d.Dh, kRing, h->fold, h->fold2, tile16 ? 16 : 32);
-  if (h->fold && !(create_flags & QINCO_CREATE_DECODE_FOLDED)) {
+  // Decode through an un-folded twin of the instance: only where that is faster -- the two-workgroups-per-CU (short-MLP) shapes
+  // (qinco2-S: 57.4 M vec/s against 54.5 M through the folded kernel).  On the 384-wide shapes the folded kernel wins once the
+  // measurement is long enough to be warm (C2 2.12 M against 2.08 M, qinco2-M 7.46 M against 6.92 M; scripts/exp_decode_twin.py):
+  // round 2 had it the other way round from 10 ms timing loops.
+  if (h->fold && (fn->var & 256) && !(create_flags & QINCO_CREATE_DECODE_FOLDED)) {
     const MlpInstance* di = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~(16 | 32));
-    if (!di || (di->var & (16 | 32)))   // (the un-folded twins are compiled with ring groups of 4)
-      di = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~(16 | 32 | 1024));
     if (di && !(di->var & (16 | 32 | 128)) && di->P == fn->P) {
       h->dec_inst = di;
       h->dec_sd = stream_dims(d.D, d.De, d.Dh, di->P, false, false, 32);

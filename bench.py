@@ -32,6 +32,7 @@ Also in the line (N = 1, measured after the timed region):
   `c1` -- BASELINE configs[0] / the north_star's literal target (qinco1 8x8, greedy): vectors/s, roofline, the number of
           code rows equal to the oracle's on a 256-vector sample, and the oracle's own rate on that sample (CPU baseline);
   `c3`, `c4` -- BASELINE configs[2] (M = 16) and configs[3] (D = 768) at their bench batch, with roofline;
+  `qinco2_S`, `ivf_qinco2_S` -- the small preset and its IVF form (ivf_K = 2^20: the reference's billion-scale family);
   `encode_db_bvecs` (C2) and `encode_db_bvecs_qinco2S` -- the actual `task=encode` data path (search_tasks.py:85-137): a uint8 .bvecs file on disk ->
           get_data_memmap -> encode_database(QINCoHIP) -> part file, i.e. host buffers / PCIe included, next to the
           HBM-resident rate of the same model.
@@ -62,7 +63,8 @@ PEAK_F16_MFMA_TFLOPS = 2516.6   # dense fp16 / bf16 MFMA peak at 2.4 GHz (16 x t
 # this port (torch backend) 42.3 vec/s, numpy oracle 9.3 vec/s -- all three give identical codes
 REF_OVER_PORT_CONTAINER = 1.10
 WORKLOAD_NAMES = {"C1": "C1: qinco1 8x8 greedy encode", "C2": "C2: qinco2-L 8x8 encode", "C3": "C3: qinco2-L 16x8 encode",
-                  "C4": "C4: qinco2-L 8x8 encode, D=768"}
+                  "C4": "C4: qinco2-L 8x8 encode, D=768", "S": "qinco2-S 8x8 encode",
+                  "IVF_S": "IVF-qinco2-S 8x8 encode, ivf_K = 2^20 (the reference's billion-scale model family)"}
 
 
 def pmc_traffic_per_row():
@@ -202,12 +204,13 @@ def leg_workload(torch, dev, name, steps, batch, oracle_sample=0):
     mean_t = torch.from_numpy(np.asarray(sd["data_mean"])).to(dev)
     std = float(sd["data_std"])
     xs = [synth_batch_device(torch, cfg, mean_t, std, batch, 7_000_003 * s + 11, dev) for s in range(steps + 1)]
-    eng.encode(xs[0], code_dtype=np.uint8)
+    cdt = np.int32 if cfg.ivf else np.uint8        # (an IVF id does not fit a byte)
+    eng.encode(xs[0], code_dtype=cdt)
     torch.cuda.synchronize(dev)
     eng.profile_enable(True)
     eng.profile_read()
     t0 = time.perf_counter()
-    codes = [eng.encode(xs[1 + s], code_dtype=np.uint8) for s in range(steps)]
+    codes = [eng.encode(xs[1 + s], code_dtype=cdt) for s in range(steps)]
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
@@ -216,6 +219,10 @@ def leg_workload(torch, dev, name, steps, batch, oracle_sample=0):
            "vectors_per_step": batch, "ms_per_step": dt / steps * 1e3, "A": cfg.A, "B": cfg.B, "M": cfg.M, "D": cfg.D,
            "gflop_per_vector": eng.flops_per_vector("encode") / 1e9,
            "roofline": roofline_dict(cfg, prof, dt, kernel="qinco::mlp_kernel (+ xproj)" if cfg.De <= 384 else "qinco::mlp16_kernel")}
+    if cfg.ivf:
+        st = eng.ivf_last_stats()
+        out["ivf"] = {"ivf_K": cfg.ivf_K, "exact_candidates_per_vector": st["candidates"] / batch, "fell_back_to_fp32_table": st["fell_back"],
+                      "note": "coarse assignment: fp16 matrix-core filter (1/8 sample, then all centroids) + exact fp32 decision (DESIGN.md 3.4)"}
     if oracle_sample:
         from oracle.qinco_oracle import OracleQINCo
         threads = cpu_threads(torch)
@@ -531,6 +538,8 @@ def main():
             for key, fn in (("c1", lambda: leg_workload(torch, dev, "C1", 3, 16384, oracle_sample=256)),
                             ("c3", lambda: leg_workload(torch, dev, "C3", 2, 16384)),
                             ("c4", lambda: leg_workload(torch, dev, "C4", 2, 16384)),
+                            ("qinco2_S", lambda: leg_workload(torch, dev, "S", 6, 16384)),
+                            ("ivf_qinco2_S", lambda: leg_workload(torch, dev, "IVF_S", 6, 16384)),
                             ("encode_db_bvecs", lambda: leg_encode_db_bvecs(torch, dev, args.bvecs_vectors, 16384)),
                             ("encode_db_bvecs_qinco2S", lambda: leg_encode_db_bvecs(torch, dev, args.bvecs_vectors, 16384, "S"))):
                 try:        # a leg can never take the headline down with it

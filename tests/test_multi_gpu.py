@@ -199,6 +199,9 @@ def test_bench_driver_line_carries_the_metric_grid():
     n_same, n_all = (int(v) for v in c1["greedy_rows_equal_to_oracle"].split("/"))
     assert n_all == 256 and n_same >= 254 and c1["cpu_baseline"]["value"] > 0 and c1["gpu_over_cpu"] > 10
     assert 0.5 < c1["roofline"]["frac_executed"] <= 1.0
+    for k in ("qinco2_S", "ivf_qinco2_S"):
+        assert "error" not in rec[k] and rec[k]["value"] > 0, rec[k]
+    assert rec["ivf_qinco2_S"]["ivf"]["ivf_K"] == 1 << 20 and not rec["ivf_qinco2_S"]["ivf"]["fell_back_to_fp32_table"]
     for k, M, D in (("c3", 16, 128), ("c4", 8, 768)):
         assert "error" not in rec[k], rec[k]
         assert rec[k]["M"] == M and rec[k]["D"] == D and rec[k]["value"] > 0 and 0.5 < rec[k]["roofline"]["frac_executed"] <= 1.0

@@ -40,7 +40,7 @@ sys.path.insert(0, "/root/reference")
 
 from cases import clustered_rows  # noqa: E402  (pure numpy: also used by the tests, which never import the reference)
 from qinco.model import QINCo  # noqa: E402  (the reference)
-from qinco.model.qinco_base import initialize_qinco_codebooks  # noqa: E402
+from qinco.model.qinco_base import IVFBook, initialize_qinco_codebooks  # noqa: E402
 from qinco.utils import SharedCfgState, save_model  # noqa: E402
 
 torch.set_num_threads(8)
@@ -82,7 +82,25 @@ SPECS = {
     # QINCo1-shaped (qinco1.yaml: de null, dh 256, A 0, B 1, qinco1_mode) with L = 4 on small-magnitude floats
     "trained_qinco1": dict(kind="small", D=128, M=4, K=256, L=4, de=None, dh=256, A=0, B=1, qinco1_mode=True,
                            steps=700, batch=192, lr=4e-4, opt="adam", clip=0.0, seed=2102),
+    # De != D: trained in_proj / out_proj (the S shape has Identity there), on a small geometry (32 -> 64, hidden 96)
+    "trained_tiny_proj": dict(kind="small", D=32, M=4, K=256, L=2, de=64, dh=96, A=8, B=8, qinco1_mode=False,
+                              steps=1200, batch=256, lr=8e-4, opt="adamw", clip=0.1, seed=2104),
+    # IVF-QINCo2-S-shaped: a frozen coarse codebook of 2048 k-means centroids in front (qinco_tasks.py:277-300), M = 4 steps after it
+    "trained_ivf_qinco2S": dict(kind="u8", D=128, M=4, K=256, L=2, de=128, dh=256, A=16, B=8, qinco1_mode=False, ivf_K=2048,
+                                steps=1000, batch=256, lr=8e-4, opt="adamw", clip=0.1, seed=2103),
 }
+
+
+def numpy_kmeans(x: np.ndarray, K: int, seed: int, iters: int = 10) -> np.ndarray:
+    """Plain Lloyd iterations on raw rows (stands in for the faiss k-means that makes the reference's IVF centroid files)."""
+    rs = np.random.RandomState(seed)
+    cent = x[rs.choice(len(x), K, replace=False)].astype(np.float32).copy()
+    for _ in range(iters):
+        a = ((x * x).sum(1)[:, None] + (cent * cent).sum(1)[None] - 2.0 * x @ cent.T).argmin(1)
+        for k in range(K):
+            sel = a == k
+            cent[k] = x[sel].mean(0) if sel.any() else x[rs.randint(len(x))]
+    return cent
 
 
 def train(name: str) -> Path:
@@ -91,18 +109,27 @@ def train(name: str) -> Path:
     D, M, K = s["D"], s["M"], s["K"]
     xtr = clustered_rows(s["kind"], 24576, D, s["seed"]).astype(np.float32)
     mean, std = xtr.mean(0).astype(np.float32), float(xtr.std())                   # qinco_tasks.py:430-431
+    ivf_K = s.get("ivf_K")
     cfg = SharedCfgState(dict(output=str(HERE / f"{name}.pt"), K=K, M=M, de=s["de"], dh=s["dh"], L=s["L"], A=s["A"], B=s["B"],
-                              ivf_in_use=None, ivf_K=None, qinco1_mode=s["qinco1_mode"], task="train", enc_max_bs=1 << 20,
-                              codebook_noise_init=0.1, inference=False, batch=s["batch"]))
-    cfg._D, cfg._M_ivf, cfg._K_vals, cfg._ivf_book = D, M, [K] * M, None
+                              ivf_in_use=(True if ivf_K else None), ivf_K=ivf_K, qinco1_mode=s["qinco1_mode"], task="train",
+                              enc_max_bs=1 << 20, codebook_noise_init=0.1, inference=False, batch=s["batch"]))
+    cfg._D, cfg._M_ivf, cfg._K_vals, cfg._ivf_book = D, M + (1 if ivf_K else 0), ([ivf_K] if ivf_K else []) + [K] * M, None
     cfg._qinco_jit = False
     cfg._accelerator = Acc()
     cfg._data_mean, cfg._data_std = mean, std
     cfg._cur_epoch = cfg._optimizer = cfg._scheduler = cfg._melog = None
+    xn = (xtr[:16384] - mean) / std
+    if ivf_K:   # initialize_model (qinco_tasks.py:277-300): raw-space centroids, stored normalised with the data's mean / std
+        cent = numpy_kmeans(xtr[:16384], ivf_K, s["seed"] + 3)
+        cent_n = ((cent - mean) / std).astype(np.float32)
+        cfg._ivf_book = IVFBook(cfg, cent_n)
+        a = ((xn * xn).sum(1)[:, None] + (cent_n * cent_n).sum(1)[None] - 2.0 * xn @ cent_n.T).argmin(1)
+        xn = xn - cent_n[a]                        # the QINCo steps quantise what the coarse centroid leaves
     model = QINCo(cfg)
-    books = numpy_rq((xtr[:16384] - mean) / std, M, K, s["seed"] + 1)
-    # initialize_qinco_codebooks expects centroids in DATA space: it normalises step 0 with the mean, the others by std only
-    rq = [torch.from_numpy(b * std + (mean if m == 0 else 0.0)).float() for m, b in enumerate(books)]
+    books = numpy_rq(xn, M, K, s["seed"] + 1)
+    # initialize_qinco_codebooks expects centroids in DATA space: without IVF it normalises step 0 with the mean, everything
+    # else by std only; with IVF the list is indexed by the non-IVF steps (get_codebooks_refs skips the IVFBook)
+    rq = [torch.from_numpy(b * std + (mean if (m == 0 and not ivf_K) else 0.0)).float() for m, b in enumerate(books)]
     initialize_qinco_codebooks(cfg, model, rq)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = (torch.optim.AdamW if s["opt"] == "adamw" else torch.optim.Adam)(params, lr=s["lr"])

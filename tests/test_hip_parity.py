@@ -83,7 +83,8 @@ SPLIT_CASES = ["tiny_proj_dh128", "C2_qinco2L_8x8_b8", "C2_qinco2L_8x8_b1", "C3_
                "C4_qinco2L_d768_b8", "C1_qinco1_8x8", "ivf_qinco2S_d128",
                # round 3: checkpoints trained by the reference, and the datasets' real normalisation magnitudes / byte inputs
                # (the split form picks its power-of-two operand scalings from the weights: this is where that could break)
-               "trained_qinco2S", "trained_qinco2S_b1", "trained_qinco1", "norm_bigann_u8", "norm_ssnpp_u8", "norm_contriever"]
+               "trained_qinco2S", "trained_qinco2S_b1", "trained_qinco1", "trained_ivf_qinco2S", "trained_tiny_proj",
+               "norm_bigann_u8", "norm_ssnpp_u8", "norm_contriever"]
 
 
 @pytest.fixture(scope="module")
@@ -757,7 +758,7 @@ def test_from_checkpoint_runs_encode_database_on_the_gpu(tmp_path):
 
 
 @pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_f16"])
-@pytest.mark.parametrize("name", ["trained_qinco2S", "trained_qinco1"])
+@pytest.mark.parametrize("name", ["trained_qinco2S", "trained_qinco1", "trained_ivf_qinco2S", "trained_tiny_proj"])
 def test_reference_trained_checkpoint_through_from_checkpoint(name, split):
     """A checkpoint the imported reference TRAINED (tests/golden/make_trained.py) and wrote with its own save_model, loaded
     through the product's checkpoint reader and run behind the reference-shaped model object -- uint8 rows for the
@@ -768,7 +769,7 @@ def test_reference_trained_checkpoint_through_from_checkpoint(name, split):
     g = load_golden(name)
     model = QINCoHIP.from_checkpoint(str(GOLDEN / CASES[name].ckpt), max_batch=100, split_f16=split)
     assert model.built and model.engine.split_f16 == split
-    if name == "trained_qinco2S":
+    if name in ("trained_qinco2S", "trained_ivf_qinco2S"):
         assert g["x"].dtype == np.uint8
     codes = np.ascontiguousarray(model(g["x"], step="encode").T)
     want = ref_codes(g)

@@ -82,8 +82,8 @@ SPECS = {
     # QINCo1-shaped (qinco1.yaml: de null, dh 256, A 0, B 1, qinco1_mode) with L = 4 on small-magnitude floats
     "trained_qinco1": dict(kind="small", D=128, M=4, K=256, L=4, de=None, dh=256, A=0, B=1, qinco1_mode=True,
                            steps=700, batch=192, lr=4e-4, opt="adam", clip=0.0, seed=2102),
-    # De != D: trained in_proj / out_proj (the S shape has Identity there), on a small geometry (32 -> 64, hidden 96)
-    "trained_tiny_proj": dict(kind="small", D=32, M=4, K=256, L=2, de=64, dh=96, A=8, B=8, qinco1_mode=False,
+    # De != D: trained in_proj / out_proj (the S shape has Identity there), on a small geometry (32 -> 64, hidden 128: the one small geometry with a split-fp16 instance too)
+    "trained_tiny_proj": dict(kind="small", D=32, M=4, K=256, L=2, de=64, dh=128, A=8, B=8, qinco1_mode=False,
                               steps=1200, batch=256, lr=8e-4, opt="adamw", clip=0.1, seed=2104),
     # IVF-QINCo2-S-shaped: a frozen coarse codebook of 2048 k-means centroids in front (qinco_tasks.py:277-300), M = 4 steps after it
     "trained_ivf_qinco2S": dict(kind="u8", D=128, M=4, K=256, L=2, de=128, dh=256, A=16, B=8, qinco1_mode=False, ivf_K=2048,

@@ -60,7 +60,8 @@ typedef struct {
   int32_t A;            /* candidates pre-selected per beam (0 = all K, QINCo1) */
   int32_t B;            /* beam size */
   int32_t qinco1_mode;  /* 1: res_codeword_coeff = 0 (qinco_inference.py:29) */
-  int32_t ivf_K;        /* 0, or IVF-QINCo: step 0 is an IVFBook of ivf_K centroids (multiple of 32, <= 2^24);
+  int32_t ivf_K;        /* 0, or IVF-QINCo: step 0 is an IVFBook of ivf_K centroids (any count up to 2^24; the kernels work on
+                           blocks of 32 centroids, rows added to fill the last block can never be the arg-min);
                            beam_0 = 1 and the first QINCo step pre-selects max(A, B) (qinco_base.py:108-112, 128-196) */
   int64_t max_batch;    /* vectors processed per internal pass (scratch is sized for it) */
 } qinco_desc;
@@ -192,7 +193,9 @@ QINCO_API int qinco_describe(qinco_handle h, char* buf, int32_t cap);
  *   qinco_shape_supported  1 if an instance for the padded shape exists right now
  *   qinco_load_instance  register the instance in the shared object `path`: ONE translation unit of csrc/mlp_inst.hip built
  *                        with -DQD= -DQDE= -DQDH= -DQP= -DQVAR= -DQINCO_INSTANCE_MODULE (hipcc -shared --offload-arch=gfx950;
- *                        the Python host does this on demand: qinco_amd.build.ensure_instance).  Loaded instances stay for the
+ *                        the Python host does this on demand: qinco_amd.build.ensure_instance).  A module also brings the
+ *                        pre-selection table and the exact IVF coarse assignment for its D (compiled in for D = 32, 96, 128,
+ *                        256, 768 only -- there with the fp16 filter in front).  Loaded instances stay for the
  *                        life of the process.  QINCO_ERR_INVALID if the file cannot be loaded or was built from other sources. */
 QINCO_API int qinco_shape_supported(int32_t D, int32_t De, int32_t Dh);
 QINCO_API int qinco_padded_shape(int32_t D, int32_t De, int32_t Dh, int32_t* out3);

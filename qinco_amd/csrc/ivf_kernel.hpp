@@ -22,6 +22,13 @@ __device__ __forceinline__ unsigned long long ivf_key(float d, int idx) {
   return ((unsigned long long)u << 32) | (unsigned)idx;
 }
 
+// largest divisor of nf that is <= cap (nf = 4 x feature blocks: at least 4)
+constexpr int ivf_ring_depth(int nf, int cap) {
+  int p = cap;
+  while (nf % p) --p;
+  return p;
+}
+
 template <int D>
 __global__ void __launch_bounds__(256)
 ivf_assign_kernel(const f32x4* __restrict__ cstream, const float* __restrict__ cnorm, int nblocks, int blocks_per_slice,
@@ -62,7 +69,7 @@ ivf_assign_kernel(const f32x4* __restrict__ cstream, const float* __restrict__ c
   // block boundary (without it every wave stalled on its 16 loads at the top of each block: 36 % of wave time in
   // s_waitcnt, matrix pipe 62 % busy).  The host pads the stream by P fragments.
   constexpr int NF = NDB * 4;                      // fragments per block of 32 centroids
-  constexpr int P = (NF % 16 != 0) ? NF : (NDB > 8 ? 8 : 16);  // ring depth (divides NF: compile-time ring slots)
+  constexpr int P = ivf_ring_depth(NF, NDB > 8 ? 8 : 16);      // ring depth (divides NF: compile-time ring slots)
   const f32x4* wp = cstream + (long)cb0 * (NF * 64) + lane;
   f32x4 ring[P];
 #pragma unroll
@@ -125,6 +132,13 @@ ivf_assign_kernel(const f32x4* __restrict__ cstream, const float* __restrict__ c
   const unsigned long long other = __shfl_xor(key, 32);
   if (other < key) key = other;
   if (valid && half == 0 && besti != 0x7fffffff) atomicMin(best + vec, key);
+}
+
+template <int D>
+inline hipError_t launch_ivf_assign_kernel(const IvfArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(ivf_assign_kernel<D>, dim3((unsigned)((a.N + 127) / 128), (unsigned)a.slices), dim3(256), 0, st, a.cstream, a.cnorm,
+                     a.nblocks, a.blocks_per_slice, a.x, a.N, a.best, a.only_if);
+  return hipGetLastError();
 }
 
 // codes0[n] = id part of the merged key (and the matching normalised centroid becomes xhat0 via gather_rows)

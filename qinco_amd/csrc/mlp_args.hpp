@@ -100,6 +100,24 @@ struct TableArgs {
   int coop;               // 1: the cooperative small-launch kernel
 };
 
+// The exact fp32 coarse assignment of an IVF model (ivf_kernel.hpp).  Compiled-in for the reference's dataset dimensions (with the
+// fp16 filter in front, ivf_f16_kernel.hpp); a module built on demand brings the fp32 kernel for its D.
+struct IvfArgs {
+  const f32x4* cstream;   // centroids as MFMA fragments (block of 32, feature block, q)
+  const float* cnorm;     // (ivf_K) |c_k|^2  (rows added to reach a multiple of 32 carry 1e30: never the minimum)
+  int nblocks, blocks_per_slice, slices;
+  const float* x;         // (N, D) normalised vectors
+  long N;
+  unsigned long long* best;   // (N) merged (distance, id) keys
+  const int* only_if;     // nullptr, or: do nothing unless *only_if != 0
+};
+
+// Source-version check between the library and a module built on demand: the sizes of the argument blocks they exchange.
+constexpr int instance_abi() {
+  return (int)((sizeof(MlpArgs) << 20) | (sizeof(XprojArgs) << 8) | sizeof(IvfArgs));
+}
+static_assert(sizeof(MlpArgs) < 2048 && sizeof(XprojArgs) < 4096 && sizeof(IvfArgs) < 256, "instance_abi packing");
+
 // 1 if the instance's xproj launcher serves XprojArgs::cstream (the fused small-launch kernel exists for the shape)
 constexpr bool presel_coop_ok(int DE, int DH, int var) {
   return (DE / 32) % 4 == 0 && (DH / 32) % 4 == 0 && DE <= 384 && (var & 16) && !(var & 128) && !(var & 512);

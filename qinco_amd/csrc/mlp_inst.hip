@@ -49,13 +49,18 @@ hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::Mlp
 }
 
 #ifdef QINCO_INSTANCE_MODULE
+#include "ivf_kernel.hpp"
 #include "table_kernel.hpp"
+extern "C" __attribute__((visibility("hidden"))) hipError_t qinco_module_ivf_launch(const qinco::IvfArgs* a, hipStream_t stream) {
+  if (a->N <= 0) return hipSuccess;
+  return qinco::launch_ivf_assign_kernel<QD>(*a, stream);
+}
 extern "C" __attribute__((visibility("hidden"))) hipError_t qinco_module_table_launch(const qinco::TableArgs* a, hipStream_t stream) {
   if (a->G <= 0) return hipSuccess;
   return qinco::launch_table_kernels<QD>(*a, stream);
 }
 // Built on demand as a shared object of its own (qinco_amd.build.ensure_instance) and registered with qinco_load_instance:
-// v = {D, De, Dh, P, VAR, 0}, fns = {mlp launcher, xproj launcher, table launcher (K = 256 pre-selection for this D)}; returns the sizes of the two argument blocks as the
+// v = {D, De, Dh, P, VAR, 0}, fns = {mlp launcher, xproj launcher, table launcher (K = 256 pre-selection for this D), IVF coarse assignment for this D}; returns instance_abi() (the sizes of the argument blocks) as the
 // source-version check (a module built against another csrc/mlp_args.hpp must not be launched).
 extern "C" hipError_t QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::XprojArgs* a, hipStream_t stream);
 extern "C" __attribute__((visibility("default"))) int qinco_instance_info(int* v, void** fns) {
@@ -67,7 +72,8 @@ extern "C" __attribute__((visibility("default"))) int qinco_instance_info(int* v
   fns[0] = reinterpret_cast<void*>(&QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR));
   fns[1] = reinterpret_cast<void*>(&QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR));
   fns[2] = reinterpret_cast<void*>(&qinco_module_table_launch);
-  return (int)((sizeof(qinco::MlpArgs) << 16) | sizeof(qinco::XprojArgs));
+  fns[3] = reinterpret_cast<void*>(&qinco_module_ivf_launch);
+  return qinco::instance_abi();
 }
 #endif
 

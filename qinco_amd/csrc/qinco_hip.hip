@@ -37,7 +37,7 @@ using namespace qinco;
 namespace qinco {
 static const MlpInstance g_instances[] = {
 #define QINCO_SHAPE(d, de, dh, p, var) \
-  {d, de, dh, p, var, &qinco_mlp_launch_##d##_##de##_##dh##_##p##_##var, &qinco_xproj_launch_##d##_##de##_##dh##_##p##_##var, nullptr},
+  {d, de, dh, p, var, &qinco_mlp_launch_##d##_##de##_##dh##_##p##_##var, &qinco_xproj_launch_##d##_##de##_##dh##_##p##_##var, nullptr, nullptr},
 #include "shapes.def"
 #undef QINCO_SHAPE
 };
@@ -59,6 +59,14 @@ const MlpInstance* find_mlp_instance(int D, int De, int Dh, int want_P, int want
   for (const MlpInstance& i : g_loaded)
     if (const MlpInstance* hit = visit(i)) return hit;
   return first;
+}
+
+static bool ivf_compiled_in(int D) { return D == 32 || D == 96 || D == 128 || D == 256 || D == 768; }
+// the exact coarse-assignment kernel a loaded module brings for its D (any module of that D will do)
+static ivf_launch_fn find_ivf_launcher(int D) {
+  for (const MlpInstance& i : g_loaded)
+    if (i.D == D && i.ivf) return i.ivf;
+  return nullptr;
 }
 
 // The kernels work on 32-feature blocks.  Any other geometry is zero-padded up to the next multiple of 32 when the weights are
@@ -124,8 +132,9 @@ struct qinco_handle_s {
   qinco_split_report calib{};                  // split form: result of the create-time calibration against the fp32 instance
   bool ever_overflowed = false;
   // IVF step 0
-  int K0 = 0;                       // rows of codebook[0] (ivf_K or K)
+  int K0 = 0;                       // rows of codebook[0] the model has (ivf_K or K): the range of step-0 codes
   f32x4* ivf_stream = nullptr;      // centroids packed as MFMA A-operand fragments
+  qinco::ivf_launch_fn ivf_module = nullptr;   // D outside the compiled-in set: the module's exact fp32 kernel (no fp16 filter)
   unsigned long long* ivf_best = nullptr;  // (max_batch) merged (distance, id) keys
   // fp16-filter passes of the IVF assignment (ivf_f16_kernel.hpp)
   bool table_valu = false;          // QINCO_CREATE_TABLE_VALU: VALU pre-selection table kernel (A/B)
@@ -363,7 +372,7 @@ static int upload_fragments(qinco_handle_s* h, const float* cb, int K, int D, f3
 
 // fp16 copy of the IVF centroids for the filter passes (ivf_f16_kernel.hpp): fragment (block of 32 centroids, k-step of
 // 16 features): lane l, 8 halfs = C[block*32 + (l & 31)][k*16 + 8 (l >> 5) + 0..7], rounded to nearest even.
-static int build_ivf_f16(qinco_handle_s* h, const float* cb) {
+static int build_ivf_f16(qinco_handle_s* h, const float* cb, int real_rows) {
   const int K = h->d.ivf_K, D = h->d.D, NK = D / 16;
   float amax = 0.f;
   double n2max = 0.0;
@@ -378,6 +387,7 @@ static int build_ivf_f16(qinco_handle_s* h, const float* cb) {
       amax = fmaxf(amax, fabsf(v));
     }
     nh[k] = -0.5f * s;  // same |c|^2 as upload_with_norms, halved exactly and negated: the filter accumulators' start value
+    if (k >= real_rows) nh[k] = -0.5f * 1e30f;   // an added row (zeros): as far away as upload_with_norms puts it
     if (s2 > n2max) n2max = s2;
   }
   if (!(amax < 60000.f)) return 0;  // outside the fp16 range: the exact fp32 kernel is used on its own
@@ -424,14 +434,16 @@ static int build_ivf_f16(qinco_handle_s* h, const float* cb) {
   return 0;
 }
 
-static int upload_with_norms(qinco_handle_s* h, const float* cb, int K, int D, float** d_cb, float** d_norm) {
+// real_rows >= 0: rows from there on were added to fill a block of 32 (all zeros) and must never win an arg-min
+static constexpr float kNeverNorm = 1e30f;
+static int upload_with_norms(qinco_handle_s* h, const float* cb, int K, int D, float** d_cb, float** d_norm, int real_rows = -1) {
   int rc = upload(h, d_cb, cb, (size_t)K * D);
   if (rc) return rc;
   std::vector<float> nrm(K);
   for (int k = 0; k < K; ++k) {
     float s = 0.f;
     for (int j = 0; j < D; ++j) s = fmaf(cb[(size_t)k * D + j], cb[(size_t)k * D + j], s);
-    nrm[k] = s;
+    nrm[k] = (real_rows >= 0 && k >= real_rows) ? kNeverNorm : s;
   }
   return upload(h, d_norm, nrm.data(), K);
 }
@@ -636,8 +648,8 @@ extern "C" int qinco_load_instance(const char* path) {
                                    "with -DQINCO_INSTANCE_MODULE?)", path);
   }
   int32_t v[6] = {0, 0, 0, 0, 0, 0};
-  void* fns[3] = {nullptr, nullptr, nullptr};
-  const int abi = info(v, fns), want_abi = (int)((sizeof(MlpArgs) << 16) | sizeof(XprojArgs));
+  void* fns[4] = {nullptr, nullptr, nullptr, nullptr};
+  const int abi = info(v, fns), want_abi = instance_abi();
   if (abi != want_abi || !fns[0] || !fns[1]) {
     dlclose(so);
     return fail(QINCO_ERR_INVALID, "qinco_load_instance: %s was built against another version of csrc/mlp_args.hpp (0x%x vs 0x%x)", path,
@@ -646,7 +658,8 @@ extern "C" int qinco_load_instance(const char* path) {
   for (const MlpInstance& i : g_loaded)
     if (i.D == v[0] && i.De == v[1] && i.Dh == v[2] && i.P == v[3] && i.var == v[4]) return QINCO_OK;   // already there
   g_loaded.push_back(MlpInstance{v[0], v[1], v[2], v[3], v[4], reinterpret_cast<mlp_launch_fn>(fns[0]),
-                                 reinterpret_cast<xproj_launch_fn>(fns[1]), reinterpret_cast<table_launch_fn>(fns[2])});
+                                 reinterpret_cast<xproj_launch_fn>(fns[1]), reinterpret_cast<table_launch_fn>(fns[2]),
+                                 reinterpret_cast<ivf_launch_fn>(fns[3])});
   return QINCO_OK;
 }
 
@@ -664,7 +677,7 @@ struct PaddedWeights {
     return dst;
   }
   // returns nullptr, or what is missing
-  const char* build(const qinco_desc& d, const qinco_weights& u, int Dp, int Dep, int Dhp) {
+  const char* build(const qinco_desc& d, const qinco_weights& u, int Dp, int Dep, int Dhp, int ivf_Kp) {
     const int M = d.M, L = d.L, D = d.D, De = d.De, Dh = d.Dh;
     if (!u.data_mean || !u.codebook) return "missing data_mean / codebook";
     w = u;
@@ -679,7 +692,7 @@ struct PaddedWeights {
     down.assign((size_t)M * (L > 0 ? L : 1), nullptr);
     for (int m = 0; m < M; ++m) {
       const long rows = (m == 0 && d.ivf_K > 0) ? d.ivf_K : d.K;
-      cb[m] = pad2d(u.codebook[m], rows, D, rows, Dp);
+      cb[m] = pad2d(u.codebook[m], rows, D, (m == 0 && d.ivf_K > 0) ? ivf_Kp : rows, Dp);   // (added centroid rows: see ivf_real)
       if (m == 0) continue;
       if (u.sub_codebook) sub[m] = pad2d(u.sub_codebook[m], d.K, D, d.K, Dp);
       if (u.in_proj) inp[m] = pad2d(u.in_proj[m], De, D, Dep, Dp);
@@ -794,22 +807,27 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   {
     int Dp, Dep, Dhp;
     padded_geometry(desc->D, desc->De, desc->Dh, &Dp, &Dep, &Dhp);
-    if (Dp != desc->D || Dep != desc->De || Dhp != desc->Dh) {
-      if (const char* why = padw.build(dpad, *w, Dp, Dep, Dhp)) return fail(QINCO_ERR_INVALID, "qinco_create: %s", why);
+    // ... and the IVF kernels on blocks of 32 centroids: a coarse codebook of any other size gets all-zero rows up to the next
+    // multiple whose squared norm is SET to 1e30 (upload_with_norms, build_ivf_f16), so that none of them is ever the arg-min
+    const int ivf_Kp = desc->ivf_K > 0 ? round_up(desc->ivf_K, 32) : desc->ivf_K;
+    if (Dp != desc->D || Dep != desc->De || Dhp != desc->Dh || ivf_Kp != desc->ivf_K) {
+      if (const char* why = padw.build(dpad, *w, Dp, Dep, Dhp, ivf_Kp)) return fail(QINCO_ERR_INVALID, "qinco_create: %s", why);
       dpad.D = Dp;
       dpad.De = Dep;
       dpad.Dh = Dhp;
+      dpad.ivf_K = ivf_Kp;
       w = &padw.w;
     }
   }
   const qinco_desc& d = dpad;
+  const int ivf_real = desc->ivf_K;      // centroids the model has; d.ivf_K - ivf_real rows were added
   if (d.K > 1024) return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: K=%d > 1024 not supported", d.K);
   if (d.A < 0 || d.A > d.K || d.B < 1) return fail(QINCO_ERR_INVALID, "qinco_create: need 0 <= A <= K and B >= 1");
-  if (d.ivf_K < 0 || d.ivf_K % 32 || d.ivf_K > (1 << 24))
-    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: ivf_K=%d must be a multiple of 32 and <= 2^24", d.ivf_K);
+  if (d.ivf_K < 0 || d.ivf_K > (1 << 24)) return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: ivf_K=%d must be in [0, 2^24]", desc->ivf_K);
   if (d.ivf_K > 0 && d.M < 2) return fail(QINCO_ERR_INVALID, "qinco_create: an IVF model needs at least one QINCo step");
-  if (d.ivf_K > 0 && d.D != 32 && d.D != 96 && d.D != 128 && d.D != 256 && d.D != 768)
-    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: no IVF kernel instance for D=%d", d.D);
+  if (d.ivf_K > 0 && !ivf_compiled_in(d.D) && !find_ivf_launcher(d.D))
+    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: no IVF kernel instance for D=%d [the model's %d in 32-feature blocks]: build a module "
+                "of that D on demand (qinco_amd.build.ensure_instance -> qinco_load_instance)", d.D, desc->D);
   if (!(w->data_std > 0.f)) return fail(QINCO_ERR_INVALID, "qinco_create: data_std must be > 0 (qinco_base.py:526)");
   const int want_P = opt.mlp_P, want_var = opt.mlp_var;  // diagnostics: a non-production instance of the shape
   const MlpInstance* fn = find_mlp_instance(d.D, d.De, d.Dh, want_P, want_var);
@@ -843,6 +861,7 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   h->A = d.A;
   h->B = d.B;
   h->inst = fn;
+  if (d.ivf_K > 0 && !ivf_compiled_in(d.D)) h->ivf_module = find_ivf_launcher(d.D);
   h->std_ = w->data_std;
   h->table_valu = (create_flags & QINCO_CREATE_TABLE_VALU) != 0;
   h->table_coop = !(create_flags & QINCO_CREATE_TABLE_NO_COOP);
@@ -892,7 +911,7 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   h->wq_stream.assign(d.M, nullptr);
   h->smul.assign(d.M, nullptr);
   h->xsmul.assign(d.M, nullptr);
-  h->K0 = d.ivf_K > 0 ? d.ivf_K : d.K;
+  h->K0 = d.ivf_K > 0 ? ivf_real : d.K;
   std::vector<int> kv(d.M, d.K);
   kv[0] = h->K0;
   if ((rc = dev_alloc(h, &h->kvals, d.M))) return bail(rc);
@@ -907,11 +926,13 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
 
   for (int m = 0; m < d.M; ++m) {
     if (!w->codebook[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: codebook[%d] is null", m));
-    if ((rc = upload_with_norms(h, w->codebook[m], m == 0 ? h->K0 : d.K, d.D, &h->codebook[m], &h->cnorm[m]))) return bail(rc);
+    if ((rc = upload_with_norms(h, w->codebook[m], (m == 0 && d.ivf_K > 0) ? d.ivf_K : d.K, d.D, &h->codebook[m], &h->cnorm[m],
+                                (m == 0 && d.ivf_K > 0) ? ivf_real : -1)))
+      return bail(rc);
     if (m == 0) {
       if (d.ivf_K > 0) {
         if ((rc = upload_fragments(h, w->codebook[0], d.ivf_K, d.D, &h->ivf_stream))) return bail(rc);
-        if (!(create_flags & QINCO_CREATE_IVF_FP32) && (rc = build_ivf_f16(h, w->codebook[0]))) return bail(rc);
+        if (!(create_flags & QINCO_CREATE_IVF_FP32) && !h->ivf_module && (rc = build_ivf_f16(h, w->codebook[0], ivf_real))) return bail(rc);
       } else if (mfma_table_ok(d, h->inst)) {
         if ((rc = upload_fragments(h, w->codebook[0], d.K, d.D, &h->cb_stream[0]))) return bail(rc);
       }
@@ -1329,7 +1350,10 @@ static int launch_ivf_assign(qinco_handle_s* h, long n, hipStream_t st) {
     int bps;
     long slices;
     ivf_grid(tiles, nblocks, 2048, &bps, &slices);  // aim at >= 2048 workgroups
-    switch (d.D) {
+    if (h->ivf_module) {
+      IvfArgs ia{h->ivf_stream, h->cnorm[0], nblocks, bps, (int)slices, h->xn, n, h->ivf_best, only_if};
+      if (h->ivf_module(&ia, st) != hipSuccess) return fail(QINCO_ERR_HIP, "IVF module launch failed");
+    } else switch (d.D) {
       case 32: launch_ivf_inst<32>(h, n, nblocks, bps, (int)slices, only_if, st); break;
       case 96: launch_ivf_inst<96>(h, n, nblocks, bps, (int)slices, only_if, st); break;
       case 128: launch_ivf_inst<128>(h, n, nblocks, bps, (int)slices, only_if, st); break;
@@ -1435,7 +1459,7 @@ static int check_common(qinco_handle h, const void* a, const void* b, int64_t n,
   if (n < 0) return fail(QINCO_ERR_INVALID, "%s: n < 0", who);
   if (n > 0 && (!a || !b)) return fail(QINCO_ERR_INVALID, "%s: null buffer", who);
   if (code_dtype < 0 || code_dtype > 2) return fail(QINCO_ERR_INVALID, "%s: bad code dtype %d", who, code_dtype);
-  if (code_dtype == QINCO_CODE_U8 && (h->d.K > 256 || h->d.ivf_K > 256))
+  if (code_dtype == QINCO_CODE_U8 && (h->d.K > 256 || h->user.ivf_K > 256))
     return fail(QINCO_ERR_INVALID, "%s: uint8 codes need K <= 256 (and no IVF column)", who);
   return 0;
 }

@@ -147,8 +147,8 @@ def test_kernel_instance_built_on_demand_and_registered(lib):
     else:
         assert so.exists() and lib.qinco_shape_supported(100, 256, 500) == 1
         mod = C.CDLL(str(so))
-        v, fns = (C.c_int32 * 6)(), (C.c_void_p * 3)()
-        assert mod.qinco_instance_info(v, fns) > (1 << 16) and list(v)[:5] == [128, 256, 512, 48, 124] and fns[0] and fns[1] and fns[2]
+        v, fns = (C.c_int32 * 6)(), (C.c_void_p * 4)()
+        assert mod.qinco_instance_info(v, fns) > (1 << 16) and list(v)[:5] == [128, 256, 512, 48, 124] and all(fns[i] for i in range(4))
         assert ensure_instance(100, 256, 500) is None             # second call: nothing to do
 
 

@@ -362,6 +362,8 @@ def test_input_formats(engines):
     dict(D=64, de=96, dh=160, L=2, A=8, B=2),                          # multiples of 32 that shapes.def does not list
     dict(D=200, de=200, dh=300, L=2, A=16, B=4),                       # De == D given explicitly; D padded to 224: the module's own MFMA table
     dict(D=100, de=None, dh=200, L=2, A=8, B=4, ivf_K=2048),           # an IVF model at a padded dimension (centroids padded too)
+    dict(D=128, de=None, dh=256, L=2, A=8, B=4, ivf_K=1000),           # a coarse codebook that is not made of blocks of 32 centroids
+    dict(D=160, de=None, dh=200, L=1, A=8, B=4, ivf_K=1000),           # ... at a dimension whose IVF kernel comes with the module
 ], ids=lambda kw: f"D{kw['D']}_de{kw['de']}_dh{kw['dh']}" + ("_ivf" if kw.get("ivf_K") else ""))
 def test_arbitrary_geometry_builds_an_instance_on_demand(kw):
     """The reference builds any (D, de, dh, L) (qinco_base.py:229-260).  Geometries outside csrc/shapes.def: QincoEngine pads
@@ -386,6 +388,12 @@ def test_arbitrary_geometry_builds_an_instance_on_demand(kw):
     assert rel_err(eng.decode(rc), oracle(rc.T, step="decode")) < REL_TOL
     assert abs(eng.flops_per_vector("encode") - cfg.encode_flops_per_vector()) < 1e-6 * cfg.encode_flops_per_vector()
     print(f"{kw}: {nbad} rows on ties")
+    if cfg.ivf and cfg.ivf_K % 32:     # the rows added to fill the last block of 32 centroids are not codes of the model
+        assert got[:, 0].max() < cfg.ivf_K and ("ivf=fp32" in eng.describe()) == (cfg.D == 160)
+        far = want[:4].copy()
+        far[:, 0] = cfg.ivf_K
+        with pytest.raises(IndexError):
+            eng.decode(far)
     eng.close()
     if cfg.D == 200:   # the VALU pre-selection table at a padded D of 224 needs > 64 KiB of dynamic LDS: keep that path alive too
         ev = QincoEngine(cfg, sd, max_batch=256, diagnostics={"table_valu": True})

@@ -825,6 +825,9 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   if (d.A < 0 || d.A > d.K || d.B < 1) return fail(QINCO_ERR_INVALID, "qinco_create: need 0 <= A <= K and B >= 1");
   if (d.ivf_K < 0 || d.ivf_K > (1 << 24)) return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: ivf_K=%d must be in [0, 2^24]", desc->ivf_K);
   if (d.ivf_K > 0 && d.M < 2) return fail(QINCO_ERR_INVALID, "qinco_create: an IVF model needs at least one QINCo step");
+  if (d.ivf_K > 0 && d.A > 0 && d.B > d.K)
+    return fail(QINCO_ERR_INVALID, "qinco_create: the first QINCo step of an IVF model pre-selects max(A, B) = %d of its K = %d codewords "
+                "(qinco_base.py:108-112; the reference's topk raises)", d.B, d.K);
   if (d.ivf_K > 0 && !ivf_compiled_in(d.D) && !find_ivf_launcher(d.D))
     return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: no IVF kernel instance for D=%d [the model's %d in 32-feature blocks]: build a module "
                 "of that D on demand (qinco_amd.build.ensure_instance -> qinco_load_instance)", d.D, desc->D);
@@ -1151,6 +1154,9 @@ extern "C" int qinco_set_beam(qinco_handle h, int32_t A, int32_t B) {
   if (A > 0 && h->d.A == 0)
     return fail(QINCO_ERR_INVALID,
                 "Can't evaluate a model trained with A=0 (no candidates pre-selection) using a non-zero A value.");
+  if (h->d.ivf_K > 0 && A > 0 && B > h->d.K)
+    return fail(QINCO_ERR_INVALID, "qinco_set_beam: the first QINCo step of an IVF model pre-selects max(A, B) = %d of its K = %d codewords", B,
+                h->d.K);
   h->A = A;
   h->B = B;
   return ensure_scratch(h);

@@ -36,7 +36,7 @@ def draw(rs: np.random.RandomState) -> dict:
     else:
         de = None if rs.rand() < 0.3 else int(rs.choice([32, 64, 72, 128, 192, 256, 320, 384, 512]))
         A = int(rs.choice([1, 2, 4, 8, 16, 32, K]))
-        B = int(rs.choice([1, 2, 4, 8, 16, 32]))
+        B = int(rs.choice([1, 2, 4, 8, 16, 32, 64, 128]))     # (beyond K for the small codebooks: beam_0 = min(B, K))
     A = min(A, K)
     dh = int(rs.choice([32, 48, 64, 128, 200, 256, 384, 512]))
     L = int(rs.choice([0, 1, 2, 2, 3, 5]))
@@ -44,7 +44,8 @@ def draw(rs: np.random.RandomState) -> dict:
     ivf_K = int(rs.choice([64, 1000, 4096])) if rs.rand() < 0.2 else None
     n = int(rs.choice([1, 7, 65, 130, 200, 200, 333]))
     max_batch = int(rs.choice([64, 128, 4096]))
-    return dict(cfg=dict(D=D, M=M, K=K, L=L, de=de, dh=dh, A=A, B=B, qinco1_mode=qinco1, ivf_K=ivf_K), n=n, max_batch=max_batch)
+    u8 = bool(rs.rand() < 0.25)        # byte rows (bvecs datasets): the library converts them itself
+    return dict(cfg=dict(D=D, M=M, K=K, L=L, de=de, dh=dh, A=A, B=B, qinco1_mode=qinco1, ivf_K=ivf_K), n=n, max_batch=max_batch, u8=u8)
 
 
 def configs(seed: int, count: int):
@@ -56,6 +57,8 @@ def configs(seed: int, count: int):
         try:
             cfg = QincoConfig(**c["cfg"])
         except (ValueError, AssertionError):
+            continue
+        if cfg.ivf and cfg.A and cfg.B > cfg.K:      # the reference's topk(max(A, B)) over K codewords raises (qinco_base.py:108-125)
             continue
         # keep the oracle's share of a case to seconds (n x beams x candidates x per-row FLOPs, fp32 numpy)
         if c["n"] * cfg.encode_flops_per_vector() > 6e10:
@@ -90,7 +93,7 @@ def main() -> int:
     def rel_err(a, b):
         a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
         return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
-    from qinco_amd import QincoEngine, synth_codes, synth_state_dict, synth_vectors
+    from qinco_amd import QincoEngine, apply_regime, regime_vectors, synth_codes, synth_state_dict, synth_vectors
     log = open(a.out, "w") if a.out else None
     failures = 0
     for i, (cfg, c) in enumerate(cases):
@@ -99,11 +102,18 @@ def main() -> int:
         try:
             sd = synth_state_dict(cfg, 5000 + 31 * a.seed + i)
             x = synth_vectors(cfg, sd, c["n"], seed=6000 + i)
+            if c.get("u8"):     # data_mean / data_std of a byte dataset's magnitude, rows clipped to [0, 255]
+                sd = apply_regime(cfg, sd, "bigann", 7000 + i)
+                x = regime_vectors(cfg, sd, c["n"], "bigann", seed=6000 + i)
+                assert x.dtype == np.uint8
             eng = QincoEngine(cfg, sd, max_batch=c["max_batch"])
             rec["describe"] = eng.describe()
             oracle = make_oracle(cfg, sd)
-            want = oracle(x, step="encode").T
+            want = oracle(x.astype(np.float32), step="encode").T
             got, xhat = eng.encode(x, return_xhat=True)
+            if i % 3 == 0:      # the narrow code types carry the same codes
+                dt = np.uint8 if max(cfg.K, cfg.ivf_K or 0) <= 256 else np.int32
+                assert np.array_equal(eng.encode(x, code_dtype=dt), got.astype(dt))
             rec["rows_on_ties"] = int(assert_only_near_ties(oracle, x, got, want, NEAR_TIE, str(c)))
             ok = (got == want).all(axis=1)
             ref = oracle(want.T, step="decode")

@@ -463,6 +463,16 @@ def test_errors_mirror_reference(engines):
     with pytest.raises(NotImplementedError):
         c2 = QincoConfig(D=64, M=2, K=256, L=1, de=1024, dh=64)
         QincoEngine(c2, synth_state_dict(c2, 1))            # wider than any kernel form holds in registers
+    # IVF: the first QINCo step pre-selects max(A, B) of its K codewords -- the reference's topk raises beyond K
+    c3 = QincoConfig(D=32, M=2, K=16, L=1, de=64, dh=96, A=2, B=32, ivf_K=64)
+    with pytest.raises(ValueError, match="pre-selects"):
+        QincoEngine(c3, synth_state_dict(c3, 1))
+    c4 = QincoConfig(D=32, M=2, K=16, L=1, de=64, dh=96, A=2, B=8, ivf_K=64)
+    e4 = QincoEngine(c4, synth_state_dict(c4, 1))
+    with pytest.raises(ValueError, match="pre-selects"):
+        e4.set_beam(B=17)
+    e4.set_beam(B=16)
+    e4.close()
 
 
 def test_set_beam_changes_search_width(engines):

@@ -114,6 +114,11 @@ def main() -> int:
             if i % 3 == 0:      # the narrow code types carry the same codes
                 dt = np.uint8 if max(cfg.K, cfg.ivf_K or 0) <= 256 else np.int32
                 assert np.array_equal(eng.encode(x, code_dtype=dt), got.astype(dt))
+            if i % 4 == 1:      # device path (torch tensors on the GPU, asynchronous) carries the same bits as the host path
+                import torch
+                cd, hd = eng.encode(torch.from_numpy(x).cuda(), return_xhat=True)
+                assert np.array_equal(cd.cpu().numpy(), got) and np.array_equal(hd.cpu().numpy(), xhat)
+                assert np.array_equal(eng.decode(torch.from_numpy(got).cuda()).cpu().numpy(), eng.decode(got))
             rec["rows_on_ties"] = int(assert_only_near_ties(oracle, x, got, want, NEAR_TIE, str(c)))
             ok = (got == want).all(axis=1)
             ref = oracle(want.T, step="decode")

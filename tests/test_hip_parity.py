@@ -924,3 +924,65 @@ def test_device_selftest_of_sort_and_selection_primitives():
     continuous data, heavy ties, NaN / inf, for the (C, T) pairs the table and beam kernels use."""
     from qinco_amd import _lib
     _lib.check(_lib.load().qinco_selftest())
+
+
+# ---- adversarial data (the sweeps of scripts/gpu_fuzz_inputs.py and scripts/gpu_fuzz_ivf.py, a compact cut of each) ---------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny_proj_beam", "trained_qinco2S", "trained_ivf_qinco2S"])
+def test_degenerate_and_extreme_rows_match_the_oracle(name):
+    """Rows a dataset does not promise to avoid: all zeros, constants, every row the same, rows that ARE reconstructions (best
+    distance ~0 at the last step), 1e4 x and 1e-6 x the data's scale, one-hot spikes, the corners of the byte cube, the data
+    mean itself, saw-teeth -- codes by the tie rule, reconstructions finite and within 1e-5."""
+    import sys
+    sys.path.insert(0, str(ROOT / "scripts"))
+    import gpu_fuzz_inputs as F
+    from qinco_amd import QincoEngine
+    cfg, sd = golden_model(name)
+    oracle = make_oracle(cfg, sd)
+    eng = QincoEngine(cfg, sd, max_batch=64)
+    rs = np.random.RandomState(11)
+    for kind in F.KINDS:
+        x = F.rows(kind, cfg, sd, oracle, rs, 72)
+        want = oracle(x.astype(np.float32), step="encode").T
+        got, xhat = eng.encode(x, return_xhat=True)
+        assert np.isfinite(xhat).all(), kind
+        assert_only_near_ties(oracle, x, got, want, NEAR_TIE, f"{name}/{kind}")
+        assert rel_err(eng.decode(want), oracle(want.T, step="decode")) < REL_TOL, kind
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["near_dup", "exact_dup", "on_centroid", "outlier", "tiny", "huge", "beyond_fp16", "x_beyond_fp16", "bytes"])
+def test_ivf_filter_survives_adversarial_codebooks(kind):
+    """The fp16 filter in front of the coarse assignment claims a rigorous bound: near-duplicate and duplicate centroids, vectors on
+    centroids, one giant centroid, magnitudes at both ends of the fp16 range and beyond it (centroids: filter off at create; inputs:
+    its flag hands the batch to the exact kernel), byte rows, 1000 centroids (not blocks of 32) -- the step-0 code is the arg-min of
+    the reference's fp32 table (qinco_base.py:146-163) or within 2e-5 of it, and the lower id on exact duplicates."""
+    import sys
+    sys.path.insert(0, str(ROOT / "scripts"))
+    import gpu_fuzz_ivf as F
+    from qinco_amd import QincoConfig, QincoEngine, synth_state_dict
+    D, K, n = 128, 1000, 700
+    rs = np.random.RandomState(F.KINDS.index(kind))
+    cfg = QincoConfig(D=D, M=1, K=256, L=1, de=None, dh=256, A=0, B=1, qinco1_mode=True, ivf_K=K)
+    sd = synth_state_dict(cfg, 77)
+    c, x, mean, std = F.make_case(rs, kind, D, K, n)
+    sd["steps.0.ivf_centroids.weight"], sd["data_mean"], sd["data_std"] = c, mean, std
+    eng = QincoEngine(cfg, sd, max_batch=512)
+    got = eng.encode(x)[:, 0]
+    st = eng.ivf_last_stats()
+    xn = ((x.astype(np.float32) - mean) / std).astype(np.float32)
+    d = (xn * xn).sum(1, dtype=np.float32)[:, None] + (c * c).sum(1, dtype=np.float32)[None] - np.float32(2) * (xn @ c.T)
+    want = d.argmin(1)
+    dgot, dmin = d[np.arange(n), got], d[np.arange(n), want]
+    terms = (xn * xn).sum(1) + (c[want] * c[want]).sum(1) + 1e-30
+    tie = ((dgot - dmin) / np.maximum(np.abs(dgot), 1e-30) < NEAR_TIE) | ((dgot - dmin) / terms < 4 * D * 2.0 ** -24)
+    assert tie.all() and got.max() < K, np.nonzero(~tie)[0][:5]
+    print(f"{kind}: {int((got != want).sum())} rows on ties, {st}")
+    if kind == "exact_dup":
+        assert not ((got >= K // 2) & (got < 2 * (K // 2))).any()
+    if kind == "beyond_fp16":
+        assert "ivf=fp32" in eng.describe()
+    if kind == "x_beyond_fp16":
+        assert st["fell_back"]
+    eng.close()

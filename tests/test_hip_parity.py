@@ -986,3 +986,45 @@ def test_ivf_filter_survives_adversarial_codebooks(kind):
     if kind == "x_beyond_fp16":
         assert st["fell_back"]
     eng.close()
+
+
+@pytest.mark.gpu
+def test_handles_on_concurrent_host_threads():
+    """One handle per host thread (a server's worker threads; ctypes drops the GIL inside the library): different models, host
+    path and device path, created, run and destroyed at the same time -- every thread gets the bits it gets alone."""
+    import threading
+    import torch
+    from qinco_amd import QincoEngine, synth_vectors
+    names = ["tiny_proj_beam", "trained_qinco2S", "tiny_ivf_beam", "C1_qinco1_8x8", "tiny_id_qinco1", "trained_tiny_proj"]
+    models = {n: golden_model(n) for n in names}
+    xs = {n: synth_vectors(models[n][0], models[n][1], 700, seed=5) for n in names}
+    alone = {}
+    for n in names:
+        e = QincoEngine(*models[n], max_batch=256)
+        alone[n] = e.encode(xs[n], return_xhat=True)
+        e.close()
+    errors = []
+
+    def worker(n, device_path):
+        try:
+            for _ in range(3):      # create / run / destroy while the others do the same
+                e = QincoEngine(*models[n], max_batch=256)
+                if device_path:
+                    with torch.cuda.stream(torch.cuda.Stream()):
+                        c, h = e.encode(torch.from_numpy(xs[n]).cuda(), return_xhat=True)
+                        torch.cuda.current_stream().synchronize()
+                    c, h = c.cpu().numpy(), h.cpu().numpy()
+                else:
+                    c, h = e.encode(xs[n], return_xhat=True)
+                assert np.array_equal(c, alone[n][0]) and np.array_equal(h, alone[n][1]), n
+                assert np.array_equal(e.decode(c), e.decode(alone[n][0]))
+                e.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append((n, device_path, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(n, i % 2 == 1)) for i, n in enumerate(names * 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

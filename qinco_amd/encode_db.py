@@ -195,7 +195,8 @@ class PartFileWriter:
         self._dos = ((lt.tm_hour << 11) | (lt.tm_min << 5) | (lt.tm_sec // 2),
                      ((max(lt.tm_year, 1980) - 1980) << 9) | (lt.tm_mon << 5) | lt.tm_mday)
         self._name = b"codes.npy"
-        self._f = open(path, "wb")
+        self._tmp = path + ".tmp"     # renamed onto `path` by close(): a part file that exists is a complete one (resume relies on it)
+        self._f = open(self._tmp, "wb")
         z64 = struct.pack("<HHQQ", 1, 16, 0, 0)                     # patched at close: uncompressed, compressed size
         self._f.write(struct.pack("<IHHHHHIIIHH", 0x04034B50, 45, 0, 8, self._dos[0], self._dos[1], 0, 0xFFFFFFFF, 0xFFFFFFFF,
                                   len(self._name), len(z64)))
@@ -259,6 +260,7 @@ class PartFileWriter:
         f.seek(self._z64_at + 4)
         f.write(struct.pack("<QQ", self._usize, self._csize))
         f.close()
+        os.replace(self._tmp, self.path)
         self._pool.shutdown()
 
 
@@ -282,7 +284,7 @@ def _barrier(dist, device=None):
 
 def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D: int, batch: int = 65536,
                     dist=None, gather: bool = False, to_device: Optional[Callable] = None, device=None,
-                    writer_threads: int = 8):
+                    writer_threads: int = 8, resume: bool = False):
     """Reference-compatible database encode.  Returns this rank's codes; with gather=True rank 0 returns the
     whole (N, M) code matrix collected with one collective (other ranks: their own shard).  `device`: where the
     collective's buffers live (default: this rank's current GPU under backend "nccl", the host under "gloo").
@@ -290,7 +292,12 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
     Files: `<output>` = np.savez_compressed(n_parts, K, M, D) by rank 0; `<base>.part_<rank>.npz` = codes
     (search_tasks.py:119-134; the reference logs `.{rank}.npz` but writes `.part_{rank}.npz`).  The part file is deflated on
     `writer_threads` threads while the shard is still being encoded (PartFileWriter; 0 = numpy's single-threaded
-    np.savez_compressed at the end, the reference's way -- same format either way)."""
+    np.savez_compressed at the end, the reference's way -- same format either way).
+
+    resume=True: a rank whose part file is already there with the right number of rows loads it instead of encoding its shard
+    again (the reference's encode_database has no resume: a crashed rank costs the whole job; part files are written under a
+    temporary name and renamed when complete, so one that exists is whole).  Every rank still takes part in the barriers and in
+    the gather."""
     assert output.endswith(".npz")
     base = output[:-4]
     rank, world = _dist_info(dist)
@@ -298,12 +305,17 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
         _barrier(dist, device)
     start, end = shard_bounds(len(db_vecs), world, rank)
     state = {"writer": None}
+    part = base + f".part_{rank}.npz"
+    done = _load_part(part, end - start) if resume else None
 
     def sink(c):   # created with the first batch: the number of code columns is the model's business (M + 1 with an IVF column)
         if state["writer"] is None:
-            state["writer"] = PartFileWriter(base + f".part_{rank}.npz", end - start, c.shape[1], writer_threads)
+            state["writer"] = PartFileWriter(part, end - start, c.shape[1], writer_threads)
         state["writer"].add(c)
-    codes = encode_shard(model, db_vecs, start, end, batch, to_device, sink if (writer_threads > 0 and end > start) else None)
+    if done is not None:
+        codes = done
+    else:
+        codes = encode_shard(model, db_vecs, start, end, batch, to_device, sink if (writer_threads > 0 and end > start) else None)
     writer = state["writer"]
     if codes.size == 0:
         codes = np.zeros((0, M), np.int64)
@@ -316,13 +328,26 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
         np.savez_compressed(output, n_parts=world, K=K, M=M, D=D)
     if writer is not None:
         writer.close()
-    else:
-        np.savez_compressed(base + f".part_{rank}.npz", codes=codes)
+    elif done is None:
+        tmp = part + ".tmp.npz"      # (np.savez appends .npz to other suffixes)
+        np.savez_compressed(tmp, codes=codes)
+        os.replace(tmp, part)
     if world > 1:
         _barrier(dist, device)
     if gather:
         return gather_codes(codes, len(db_vecs), dist, device=device)
     return codes
+
+
+def _load_part(path: str, rows: int) -> Optional[np.ndarray]:
+    """The codes of a finished part file, or None (missing, unreadable, or of another shard size)."""
+    if not os.path.exists(path):
+        return None
+    try:
+        codes = np.load(path)["codes"]
+    except Exception:      # a truncated / foreign file: encode the shard again
+        return None
+    return codes if codes.ndim == 2 and len(codes) == rows else None
 
 
 def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None) -> Optional[np.ndarray]:

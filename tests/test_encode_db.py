@@ -81,6 +81,41 @@ def test_encode_database_single_process_files(tmp_path):
         EncodedDBIterator(out, M=cfg.M + 1)
 
 
+@pytest.mark.parametrize("threads", [4, 0])
+def test_encode_database_resume_skips_finished_part_files(tmp_path, threads):
+    """The reference's encode_database has no resume (SURVEY: a crashed rank loses the job).  Part files are written under a
+    temporary name and renamed when whole; resume=True loads a finished part instead of encoding the shard again, and
+    encodes it again when the file is missing, truncated or of another size."""
+    from qinco_amd import synth_vectors
+    from qinco_amd.encode_db import encode_database
+    model = OracleModel("tiny_proj_greedyA")
+    cfg = model.cfg
+    db = synth_vectors(cfg, model.sd, 150, seed=4)
+    calls = []
+
+    def counting(x, step):
+        calls.append(len(x))
+        return model(x, step)
+    out = str(tmp_path / "db.npz")
+    part = out[:-4] + ".part_0.npz"
+    kw = dict(K=cfg.K, M=cfg.M, D=cfg.D, batch=64, writer_threads=threads)
+    first = encode_database(counting, db, out, **kw)
+    assert sum(calls) == 150 and os.path.exists(part) and not [f for f in os.listdir(tmp_path) if ".tmp" in f]
+    calls.clear()
+    again = encode_database(counting, db, out, resume=True, **kw)
+    assert not calls and np.array_equal(again, first)                     # nothing encoded, same codes
+    blob = open(part, "rb").read()
+    open(part, "wb").write(blob[: len(blob) // 2])                          # a truncated file is not a finished one
+    redone = encode_database(counting, db, out, resume=True, **kw)
+    assert sum(calls) == 150 and np.array_equal(redone, first) and np.array_equal(np.load(part)["codes"], first)
+    calls.clear()
+    encode_database(counting, db[:100], out, resume=True, **kw)            # another shard size: encoded again
+    assert sum(calls) == 100 and len(np.load(part)["codes"]) == 100
+    calls.clear()
+    encode_database(counting, db[:100], out, **kw)                         # resume is opt-in
+    assert sum(calls) == 100
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -124,6 +159,47 @@ def test_sharded_encode_equals_single_process_gloo(tmp_path, world, n):
     for r in range(world):
         s, e = shard_bounds(n, world, r)
         assert len(np.load(tmp_path / f"db.part_{r}.npz")["codes"]) == e - s
+
+
+def _resume_worker(rank, world, port, outdir, n):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qinco_amd import synth_vectors
+    from qinco_amd.encode_db import encode_database
+    model = OracleModel("tiny_proj_greedyA")
+    cfg = model.cfg
+    db = synth_vectors(cfg, model.sd, n, seed=4)
+    rows = []
+
+    def counting(x, step):
+        rows.append(len(x))
+        return model(x, step)
+    full = encode_database(counting, db, os.path.join(outdir, "db.npz"), K=cfg.K, M=cfg.M, D=cfg.D, batch=50, dist=dist, gather=True,
+                           resume=True)
+    open(os.path.join(outdir, f"rows_{rank}.txt"), "w").write(str(sum(rows)))
+    if rank == 0:
+        np.save(os.path.join(outdir, "gathered_resume.npy"), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_resume_after_one_rank_was_lost_gloo(tmp_path):
+    """Three ranks, the part file of rank 1 is gone (the rank died): a second run with resume=True encodes that shard only, every
+    rank still meets the barriers and the gather, and rank 0 gets the same matrix."""
+    import torch.multiprocessing as mp
+    from qinco_amd.encode_db import shard_bounds
+    world, n = 3, 160
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n), nprocs=world, join=True)
+    os.remove(tmp_path / "db.part_1.npz")
+    mp.spawn(_resume_worker, args=(world, _free_port(), str(tmp_path), n), nprocs=world, join=True)
+    s, e = shard_bounds(n, world, 1)
+    assert [int(open(tmp_path / f"rows_{r}.txt").read()) for r in range(world)] == [0, e - s, 0]
+    assert np.array_equal(np.load(tmp_path / "gathered_resume.npy"), np.load(tmp_path / "gathered.npy"))
+    assert len(np.load(tmp_path / "db.part_1.npz")["codes"]) == e - s
 
 
 def test_part_file_writer_is_the_reference_format(tmp_path):

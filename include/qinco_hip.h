@@ -102,9 +102,7 @@ enum {
   QINCO_CREATE_DECODE_FOLDED = 8,
   QINCO_CREATE_TABLE_NO_COOP = 16,
   QINCO_CREATE_SPLIT_NO_CALIBRATION = 32,  /* skip the create-time comparison with the fp32 instance (below) */
-  QINCO_CREATE_NO_PRESEL_FUSION = 64,      /* diagnostics: pre-selection table and xproj as two launches at every launch size */
-  QINCO_CREATE_PRESEL_SIDE_STREAM = 128    /* large launches: the step's pre-selection runs on a second stream beside xproj (fork /
-                                              join with events on the caller's stream); off by default -- see DESIGN.md 3.2c */
+  QINCO_CREATE_NO_PRESEL_FUSION = 64       /* diagnostics: pre-selection table and xproj as two launches at every launch size */
 };
 
 /* The split form checks itself.  (1) At create, unless QINCO_CREATE_SPLIT_NO_CALIBRATION: the model is also built as an fp32

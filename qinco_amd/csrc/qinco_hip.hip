@@ -139,8 +139,6 @@ struct qinco_handle_s {
   // fp16-filter passes of the IVF assignment (ivf_f16_kernel.hpp)
   bool table_valu = false;          // QINCO_CREATE_TABLE_VALU: VALU pre-selection table kernel (A/B)
   bool table_coop = true;           // small launches: the cooperative table kernel (QINCO_CREATE_TABLE_NO_COOP clears it)
-  hipStream_t side = nullptr;       // QINCO_CREATE_PRESEL_SIDE_STREAM: where a large step's pre-selection runs while xproj runs on the caller's
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool no_presel_fusion = false;    // QINCO_CREATE_NO_PRESEL_FUSION: pre-selection and xproj as two launches at every size (A/B)
   long table_coop_max = 16384;      // ... up to this many groups
   bool ivf_f16 = false;
@@ -735,8 +733,7 @@ struct CreateOpts {
   long table_coop_max = -1;
 };
 static const int kCreateFlagMask = QINCO_CREATE_SPLIT_F16 | QINCO_CREATE_IVF_FP32 | QINCO_CREATE_TABLE_VALU | QINCO_CREATE_DECODE_FOLDED |
-                                   QINCO_CREATE_TABLE_NO_COOP | QINCO_CREATE_SPLIT_NO_CALIBRATION | QINCO_CREATE_NO_PRESEL_FUSION |
-                                   QINCO_CREATE_PRESEL_SIDE_STREAM;
+                                   QINCO_CREATE_TABLE_NO_COOP | QINCO_CREATE_SPLIT_NO_CALIBRATION | QINCO_CREATE_NO_PRESEL_FUSION;
 
 static void env_opts(CreateOpts& o) {
 #ifdef QINCO_EXPERIMENT
@@ -872,14 +869,6 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   h->table_valu = (create_flags & QINCO_CREATE_TABLE_VALU) != 0;
   h->table_coop = !(create_flags & QINCO_CREATE_TABLE_NO_COOP);
   h->no_presel_fusion = (create_flags & QINCO_CREATE_NO_PRESEL_FUSION) != 0;
-  if (create_flags & QINCO_CREATE_PRESEL_SIDE_STREAM) {
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
-      qinco_destroy(h);
-      return fail(QINCO_ERR_HIP, "qinco_create: side stream / events could not be created");
-    }
-  }
   if (opt.table_coop_max >= 0) h->table_coop_max = opt.table_coop_max;
   const int kRing = fn ? fn->P : 8;
   h->fold = fn && (fn->var & 16);
@@ -1154,9 +1143,6 @@ extern "C" int qinco_destroy(qinco_handle h) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
   }
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
   return QINCO_OK;
 }
@@ -1203,8 +1189,7 @@ static bool presel_fused(const qinco_handle_s* h, long G) {
          mfma_table_ok(h->d, h->inst) && presel_coop_ok(h->d.De, h->d.Dh, h->inst->var) && !h->no_presel_fusion;
 }
 
-static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool decode = false, const PreselJob* pj = nullptr,
-                      hipEvent_t join = nullptr) {
+static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool decode = false, const PreselJob* pj = nullptr) {
   const bool unfolded = decode && h->dec_inst;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->prof) {   // the bracket covers xproj + mlp: all the work the algorithmic FLOP count stands for
@@ -1260,7 +1245,6 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
     a.timeline = h->tl;
   }
 #endif
-  if (join) HIP_TRY(hipStreamWaitEvent(st, join, 0));   // the candidate ids come from the side stream
   HIP_TRY((unfolded ? h->dec_inst : h->inst)->fn(&a, st));
   if (h->prof) {
     HIP_TRY(hipEventRecord(e1, st));
@@ -1417,7 +1401,6 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
     const long G = (long)n * F;
     const int* cand_ids = nullptr;
     PreselJob pj;
-    hipEvent_t join = nullptr;
     const bool fused = A > 0 && presel_fused(h, G);
     if (fused) {   // small launch: the table + top-A ride in the xproj launch
       pj.x = h->xn;
@@ -1428,22 +1411,9 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
       pj.ids = h->top_ids;
       cand_ids = h->top_ids;
     } else if (A > 0) {
-      // side stream: the table + top-A (latency chains, matrix pipe ~40 % busy) runs beside xproj (matrix-pipe bound); both only
-      // read xhat, the MLP launch waits for both
-      const bool aside = h->side && h->fold;
-      hipStream_t ps = st;
-      if (aside) {
-        HIP_TRY(hipEventRecord(h->ev_fork, st));
-        HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        ps = h->side;
-      }
       if ((rc = launch_dist_topk(h, h->xn, h->xhat[cur], F, h->sub_codebook[m], h->sub_stream[m], h->sub_cnorm[m], G, Am, h->top_ids,
-                                 ps)))
+                                 st)))
         return rc;
-      if (aside) {
-        HIP_TRY(hipEventRecord(h->ev_join, h->side));
-        join = h->ev_join;
-      }
       cand_ids = h->top_ids;
     }
     MlpArgs a{};
@@ -1460,7 +1430,7 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
     a.dist_out = h->dist;
     a.add_c = d.qinco1_mode ? 0 : 1;
     a.uproj = h->uproj;
-    if ((rc = launch_mlp(h, a, m, st, false, fused ? &pj : nullptr, join))) return rc;
+    if ((rc = launch_mlp(h, a, m, st, false, fused ? &pj : nullptr))) return rc;
     const int C = F * Ae;
     const int T = Fout_cfg < C ? Fout_cfg : C;
     const size_t lds = (size_t)4 * (((C + T + 3) & ~3) + 2 * SEL_SURV) * sizeof(float);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Round 3: a large step's pre-selection (table + top-A: latency chains, matrix pipe ~40 % busy) on a second stream beside
+"""Round 3 (needs scripts/patches/r03_side_stream.patch applied; rejected, see profiles/r03_exp_side_stream.log): a large step's pre-selection (table + top-A: latency chains, matrix pipe ~40 % busy) on a second stream beside
 xproj (matrix-pipe bound) -- QINCO_CREATE_PRESEL_SIDE_STREAM against the single-stream order; vec/s decides, codes must not change."""
 import sys, time
 from pathlib import Path

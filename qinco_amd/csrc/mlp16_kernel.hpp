@@ -29,12 +29,17 @@ namespace qinco {
 
 // GK = DMAs per wave per ring boundary: 1 = a barrier / refill every 4 fragments (round 2), 2 = every 8 (VAR bit 1024; see
 // mlp_kernel.hpp G8 -- a fragment feeds only 128 matrix-pipe cycles here, so the boundary is twice as expensive per FLOP).
-template <int D, int DE, int DH, int P, int GK = 1>
+// FOLD (VAR bit 16, round 3): the row-independent head leaves the kernel like in mlp_kernel's FOLD form -- z starts as
+// T[cid] + U[group] (T per codeword: z_k + W_cat[:, :De] z_k + b, built at create; U per (vector, beam) group: W_cat[:, De:] xhat, by
+// this kernel's MODE 1), so in_proj / bias / concat are neither in the stream nor executed: 2 (De + D) De of the row's FLOPs (16 % of
+// a QINCo1 row at D = 768).
+// MODE 1 = the group projection alone: rows are groups, y = W_x . xhat through the same ring, stored to a.uproj (stream = wx).
+template <int D, int DE, int DH, int P, int GK = 1, bool FOLD = false, int MODE = 0>
 __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
   constexpr int GM = 4 * GK - 1;   // fragment-index mask of a ring group
   static_assert(GK == 1 || GK == 2 || GK == 4, "ring groups of 4, 8 or 16 fragments (16: measured, no gain over 8)");
   static_assert(P % 12 == 0 && P % (4 * GK) == 0 && P / 4 >= 2 * GK + 3, "ring depth against the group size");
-  constexpr StreamDims SL = stream_dims(D, DE, DH, P, false, false, 16);
+  constexpr StreamDims SL = stream_dims(D, DE, DH, P, FOLD, false, 16);
   constexpr int NDB = SL.NDB, NEB = SL.NEB, NHB = SL.NHB;  // 16-feature blocks
   constexpr bool PROJ = SL.PROJ;
   constexpr int NYB0 = NHB > NEB ? NHB : NEB;
@@ -113,6 +118,28 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
   f32x4 z[NEB];
   f32x4 y[NYB];
 
+  if constexpr (MODE == 1) {   // U[g] = W_cat[:, De:] xhat_g   (a.A == 1: row == group)
+    constexpr int T_X = round_up(NEB * NDB, P);
+    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { y[ob] = zero4; });
+    f32x4 xb = load_blk(xhptr);
+    static_for<NDB>([&]<int ib>() QINCO_LAMBDA {
+      const f32x4 b = xb;
+      if constexpr (ib + 1 < NDB) xb = load_blk(xhptr + (ib + 1) * 16);
+      static_for<NEB>([&]<int ob>() QINCO_LAMBDA { fragmm.template operator()<ib * NEB + ob>(y[ob], b); });
+    });
+    section_done();
+    skip_pad.template operator()<NEB * NDB, T_X>();
+    float* up = const_cast<float*>(a.uproj) + row * DE + kg * 4;
+    if (valid) static_for<NEB>([&]<int ob>() QINCO_LAMBDA { *reinterpret_cast<f32x4*>(up + ob * 16) = y[ob]; });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  if constexpr (FOLD) {
+    const float* tptr = a.ttab + (long)cid * DE + kg * 4;
+    const float* uptr = a.uproj + g * DE + kg * 4;
+    static_for<NEB>([&]<int ib>() QINCO_LAMBDA { z[ib] = load_blk(tptr + ib * 16) + load_blk(uptr + ib * 16); });
+  } else {
   // ---- A: z = in_proj(c) ----------------------------------------------------------------------------------
   if constexpr (PROJ) {
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = zero4; });
@@ -155,6 +182,7 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
     wp += SL.T_CAT * 64;
     static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = z[ob] + y[ob]; });
   }
+  }   // !FOLD
 
   // ---- D: L residual FFN blocks: z = z + W_down . relu(W_up . z)   (QBlockFFN.forward :93-97) ---------------
 #pragma unroll 1

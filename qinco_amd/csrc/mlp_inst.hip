@@ -39,7 +39,8 @@ hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::Mlp
 #elif (QVAR & 128)  // 16-row tile form (mlp16_kernel.hpp)
   const long tiles = (a->R + 15) / 16;
   const unsigned grid = (unsigned)((tiles + 3) / 4);
-  hipLaunchKernelGGL((qinco::mlp16_kernel<QD, QDE, QDH, QP, (QVAR & 1024) ? 2 : 1>), dim3(grid), dim3(256), kExclusiveLds, stream, *a);
+  hipLaunchKernelGGL((qinco::mlp16_kernel<QD, QDE, QDH, QP, (QVAR & 1024) ? 2 : 1, (QVAR & 16) != 0>), dim3(grid), dim3(256), kExclusiveLds,
+                     stream, *a);
 #else
   const long tiles = (a->R + 31) / 32;
   const unsigned grid = (unsigned)((tiles + 3) / 4);
@@ -84,10 +85,22 @@ hipError_t QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::X
   const unsigned grid = (unsigned)((a->G + 127) / 128);
   hipLaunchKernelGGL((qinco::xproj_split_kernel<QD, QDE, QDH, QP>), dim3(grid), dim3(256), 0, stream, *a);
   return hipGetLastError();
+#elif (QVAR & 128) && (QVAR & 16)   // folded 16-row form: U = W_cat[:, De:] xhat per group, the MLP kernel's MODE 1
+  if (a->G <= 0) return hipSuccess;
+  qinco::MlpArgs m{};
+  m.wstream = a->wx;
+  m.xhat = a->xhat;
+  m.uproj = a->uproj;
+  m.R = a->G;
+  m.A = 1;
+  m.F = 1;
+  const unsigned grid = (unsigned)(((a->G + 15) / 16 + 3) / 4);
+  hipLaunchKernelGGL((qinco::mlp16_kernel<QD, QDE, QDH, QP, (QVAR & 1024) ? 2 : 1, true, 1>), dim3(grid), dim3(256), kExclusiveLds, stream, m);
+  return hipGetLastError();
 #elif (QVAR & 128)
   (void)a;
   (void)stream;
-  return hipErrorNotSupported;  // the 16-row form is never folded
+  return hipErrorNotSupported;  // (the un-folded 16-row form has no group projection)
 #else
   if (a->G <= 0) return hipSuccess;
   if (a->cstream) {   // small launch with the step's pre-selection fused in (the host checked presel_coop_ok for this instance)

@@ -274,14 +274,16 @@ static void pack_bias(std::vector<float>& s, const float* b, int O, int T) {
 
 // 16-row tile form (mlp16_kernel.hpp): fragment (ob, ib) = the 16 x 16 weight block, lane l, component r =
 // W[ob*16 + (l & 15)][ib*16 + 4 (l >> 4) + r]; every section K-outer (for ib: for ob).
-static void pack16_kouter(std::vector<float>& s, const float* W, int O, int I, int T) {
+// (ld: row stride of W when it is a column range of a wider matrix; 0 = I)
+static void pack16_kouter(std::vector<float>& s, const float* W, int O, int I, int T, int ld = 0) {
   size_t start = s.size();
+  if (ld == 0) ld = I;
   for (int ib = 0; ib < I / 16; ++ib)
     for (int ob = 0; ob < O / 16; ++ob) {
       size_t base = s.size();
       s.resize(base + 256);
       for (int l = 0; l < 64; ++l)
-        for (int r = 0; r < 4; ++r) s[base + l * 4 + r] = W[(size_t)(ob * 16 + (l & 15)) * I + ib * 16 + 4 * (l >> 4) + r];
+        for (int r = 0; r < 4; ++r) s[base + l * 4 + r] = W[(size_t)(ob * 16 + (l & 15)) * ld + ib * 16 + 4 * (l >> 4) + r];
     }
   pad_to(s, start, T);
 }
@@ -537,9 +539,15 @@ static int build_fold_tables(qinco_handle_s* h, const qinco_weights* w, int m) {
   if (rc) return rc;
   std::vector<float> s;
   s.reserve((size_t)De * D);
-  for (int ob = 0; ob < De / 32; ++ob)
-    for (int ib = 0; ib < D / 32; ++ib)
-      for (int q = 0; q < 4; ++q) put_frag(s, wc + De, I, ob, ib, q);
+  if (h->inst->var & 128) {   // 16-row form: the projection runs through mlp16_kernel's own ring (MODE 1), K-outer fragments
+    const int P = h->inst->P;
+    pack16_kouter(s, wc + De, De, D, qinco::round_up((De / 16) * (D / 16), P), I);
+    s.resize(s.size() + (size_t)P * 256, 0.f);   // the ring prefetches P fragments past the end
+  } else {
+    for (int ob = 0; ob < De / 32; ++ob)
+      for (int ib = 0; ib < D / 32; ++ib)
+        for (int q = 0; q < 4; ++q) put_frag(s, wc + De, I, ob, ib, q);
+  }
   float* ds = nullptr;
   if ((rc = upload(h, &ds, s.data(), s.size()))) return rc;
   h->wx_stream[m] = reinterpret_cast<f32x4*>(ds);
@@ -954,9 +962,13 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
       return bail(fail(QINCO_ERR_INVALID, "qinco_create: in/out_proj[%d] is null", m));
     if (!w->cat_w[m] || !w->cat_b[m]) return bail(fail(QINCO_ERR_INVALID, "qinco_create: concat weights[%d] null", m));
     if (tile16) {
-      if (sd.PROJ) pack16_kouter(s, w->in_proj[m], d.De, d.D, sd.T_IN);
-      pack16_bias(s, w->cat_b[m], d.De, sd.T_BIAS);
-      pack16_kouter(s, w->cat_w[m], d.De, d.De + d.D, sd.T_CAT);
+      if (h->fold) {
+        if ((rc = build_fold_tables(h, w, m))) return bail(rc);
+      } else {
+        if (sd.PROJ) pack16_kouter(s, w->in_proj[m], d.De, d.D, sd.T_IN);
+        pack16_bias(s, w->cat_b[m], d.De, sd.T_BIAS);
+        pack16_kouter(s, w->cat_w[m], d.De, d.De + d.D, sd.T_CAT);
+      }
       for (int l = 0; l < d.L; ++l) {
         const float* up = w->up[(size_t)m * d.L + l];
         const float* dn = w->down[(size_t)m * d.L + l];

@@ -627,7 +627,8 @@ def test_model_without_ffn_blocks(kw, split):
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [None, (48, 196), (48, 1220)], ids=["production", "tile16", "tile16_groups_of_8"])
+@pytest.mark.parametrize("variant", [None, (48, 196), (48, 1220), (48, 1236)],
+                         ids=["production", "tile16", "tile16_groups_of_8", "tile16_folded"])
 def test_small_models_at_large_batches_are_exact_and_deterministic(variant):
     """Small models leave room for several workgroups per CU; the ring kernels must stay exact there (the 16-row kernel
     gave rare per-wave corruption with 3 workgroups per CU until its launch was made exclusive, csrc/mlp_inst.hip)."""
@@ -648,6 +649,7 @@ def test_small_models_at_large_batches_are_exact_and_deterministic(variant):
         assert_only_near_ties(oracle, x, runs[0][0], want, NEAR_TIE, f"small model {kw}")
         ref = (oracle(runs[0][0].T, step="decode") - oracle.data_mean) / oracle.data_std
         assert np.abs(runs[0][1] - ref).max() / np.abs(ref).max() < REL_TOL
+        assert rel_err(eng.decode(want), oracle(want.T, step="decode")) < REL_TOL       # (decode takes the same kernel form)
         eng.close()
 
 

@@ -126,7 +126,7 @@ def instance_plan(Dp: int, Dep: int, Dhp: int) -> tuple[int, int]:
     if Dep <= 384 and Dhp <= 512 and Dep + Dhp <= 768:
         return (48, 380) if (Dep <= 128 and Dhp <= 256) else (48, 124)
     if Dep <= 768 and max(Dep, Dhp) <= 1024:
-        return (48, 1268)     # 16-row tile form, ring groups of 8, folded head and first up-projection
+        return (48, 1236)     # 16-row tile form, ring groups of 8, folded head
     raise NotImplementedError(f"no kernel form for De={Dep}, Dh={Dhp}: the 16-row tile kernel holds De/4 + max(De, Dh)/4 registers "
                               "of activations per lane (De <= 768, Dh <= 1024)")
 

@@ -34,20 +34,15 @@ namespace qinco {
 // this kernel's MODE 1), so in_proj / bias / concat are neither in the stream nor executed: 2 (De + D) De of the row's FLOPs (16 % of
 // a QINCo1 row at D = 768).
 // MODE 1 = the group projection alone: rows are groups, y = W_x . xhat through the same ring, stored to a.uproj (stream = wx).
-// FOLD2 (VAR bit 32, with FOLD): the first FFN block's up-projection is linear in z = T + U too: y = relu(P[cid] + Q[group]),
-// P = W_up[0] T per codeword (create), Q = W_up[0] U per group (MODE 1, chained on U while it is still in registers -- the C/D layout
-// of one layer is the B-operand layout of the next) -- 2 De Dh more FLOPs per row that are neither streamed nor executed.
-template <int D, int DE, int DH, int P, int GK = 1, bool FOLD = false, int MODE = 0, bool FOLD2 = false>
+template <int D, int DE, int DH, int P, int GK = 1, bool FOLD = false, int MODE = 0>
 __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
-  static_assert(!FOLD2 || FOLD, "FOLD2 peels the first up-projection of a folded head");
   constexpr int GM = 4 * GK - 1;   // fragment-index mask of a ring group
   static_assert(GK == 1 || GK == 2 || GK == 4, "ring groups of 4, 8 or 16 fragments (16: measured, no gain over 8)");
   static_assert(P % 12 == 0 && P % (4 * GK) == 0 && P / 4 >= 2 * GK + 3, "ring depth against the group size");
-  constexpr StreamDims SL = stream_dims(D, DE, DH, P, FOLD, FOLD2, 16);
+  constexpr StreamDims SL = stream_dims(D, DE, DH, P, FOLD, false, 16);
   constexpr int NDB = SL.NDB, NEB = SL.NEB, NHB = SL.NHB;  // 16-feature blocks
   constexpr bool PROJ = SL.PROJ;
-  // y holds the concat Linear's output (De wide) only when the head is computed here (or U in MODE 1); folded, it is the hidden layer's
-  constexpr int NYB0 = (FOLD && MODE == 0) ? NHB : (NHB > NEB ? NHB : NEB);
+  constexpr int NYB0 = NHB > NEB ? NHB : NEB;
   constexpr int NYB = (PROJ && NDB > NYB0) ? NDB : NYB0;
 
   const int lane = threadIdx.x & 63;
@@ -136,17 +131,6 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
     skip_pad.template operator()<NEB * NDB, T_X>();
     float* up = const_cast<float*>(a.uproj) + row * DE + kg * 4;
     if (valid) static_for<NEB>([&]<int ob>() QINCO_LAMBDA { *reinterpret_cast<f32x4*>(up + ob * 16) = y[ob]; });
-    if constexpr (FOLD2) {   // Q[g] = W_up[0] U[g]: the next section of the same stream, U (in y) as the B operands
-      wp += T_X * 64;
-      f32x4 q[NHB];
-      static_for<NHB>([&]<int ob>() QINCO_LAMBDA { q[ob] = zero4; });
-      static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
-        static_for<NHB>([&]<int ob>() QINCO_LAMBDA { fragmm.template operator()<ib * NHB + ob>(q[ob], y[ib]); });
-      });
-      section_done();
-      float* qp = const_cast<float*>(a.qproj) + row * DH + kg * 4;
-      if (valid) static_for<NHB>([&]<int ob>() QINCO_LAMBDA { *reinterpret_cast<f32x4*>(qp + ob * 16) = q[ob]; });
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
@@ -203,27 +187,16 @@ __global__ void __launch_bounds__(256, 1) mlp16_kernel(MlpArgs a) {
   // ---- D: L residual FFN blocks: z = z + W_down . relu(W_up . z)   (QBlockFFN.forward :93-97) ---------------
 #pragma unroll 1
   for (int l = 0; l < a.L; ++l) {
-    if (FOLD2 && l == 0) {   // block 0's hidden layer from the tables (the stream starts with its down-projection); the host runs
-                             // L >= 1: a model without blocks gets one all-zero block.  One copy of each section's code: a peeled
-                             // block 0 cost 56 bytes of scratch per lane.
-      const float* pptr = a.ptab + (long)cid * DH + kg * 4;
-      const float* qptr = a.qproj + g * DH + kg * 4;
-      static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
-        y[ob] = load_blk(pptr + ob * 16) + load_blk(qptr + ob * 16);
-        static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob][e] = relu1(y[ob][e]); });
-      });
-    } else {
-      static_for<NHB>([&]<int ob>() QINCO_LAMBDA { y[ob] = zero4; });
-      static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
-        static_for<NHB>([&]<int ob>() QINCO_LAMBDA { fragmm.template operator()<ib * NHB + ob>(y[ob], z[ib]); });
-      });
-      static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
-        static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob][e] = relu1(y[ob][e]); });
-      });
-      section_done();
-      skip_pad.template operator()<NEB * NHB, SL.T_UP>();
-      wp += SL.T_UP * 64;
-    }
+    static_for<NHB>([&]<int ob>() QINCO_LAMBDA { y[ob] = zero4; });
+    static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
+      static_for<NHB>([&]<int ob>() QINCO_LAMBDA { fragmm.template operator()<ib * NHB + ob>(y[ob], z[ib]); });
+    });
+    static_for<NHB>([&]<int ob>() QINCO_LAMBDA {
+      static_for<4>([&]<int e>() QINCO_LAMBDA { y[ob][e] = relu1(y[ob][e]); });
+    });
+    section_done();
+    skip_pad.template operator()<NEB * NHB, SL.T_UP>();
+    wp += SL.T_UP * 64;
     // the down-projection accumulates straight into z: the residual add is the MFMA's C operand
     static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
       static_for<NEB>([&]<int ob>() QINCO_LAMBDA { fragmm.template operator()<ib * NEB + ob>(z[ob], y[ib]); });

@@ -39,8 +39,8 @@ hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::Mlp
 #elif (QVAR & 128)  // 16-row tile form (mlp16_kernel.hpp)
   const long tiles = (a->R + 15) / 16;
   const unsigned grid = (unsigned)((tiles + 3) / 4);
-  hipLaunchKernelGGL((qinco::mlp16_kernel<QD, QDE, QDH, QP, (QVAR & 1024) ? 2 : 1, (QVAR & 16) != 0, 0, (QVAR & 32) != 0>), dim3(grid), dim3(256),
-                     kExclusiveLds, stream, *a);
+  hipLaunchKernelGGL((qinco::mlp16_kernel<QD, QDE, QDH, QP, (QVAR & 1024) ? 2 : 1, (QVAR & 16) != 0>), dim3(grid), dim3(256), kExclusiveLds,
+                     stream, *a);
 #else
   const long tiles = (a->R + 31) / 32;
   const unsigned grid = (unsigned)((tiles + 3) / 4);
@@ -91,13 +91,11 @@ hipError_t QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::X
   m.wstream = a->wx;
   m.xhat = a->xhat;
   m.uproj = a->uproj;
-  m.qproj = a->qproj;     // (FOLD2: Q = W_up[0] U behind U, second section of the same stream)
   m.R = a->G;
   m.A = 1;
   m.F = 1;
   const unsigned grid = (unsigned)(((a->G + 15) / 16 + 3) / 4);
-  hipLaunchKernelGGL((qinco::mlp16_kernel<QD, QDE, QDH, QP, (QVAR & 1024) ? 2 : 1, true, 1, (QVAR & 32) != 0>), dim3(grid), dim3(256), kExclusiveLds,
-                     stream, m);
+  hipLaunchKernelGGL((qinco::mlp16_kernel<QD, QDE, QDH, QP, (QVAR & 1024) ? 2 : 1, true, 1>), dim3(grid), dim3(256), kExclusiveLds, stream, m);
   return hipGetLastError();
 #elif (QVAR & 128)
   (void)a;

@@ -542,11 +542,6 @@ static int build_fold_tables(qinco_handle_s* h, const qinco_weights* w, int m) {
   if (h->inst->var & 128) {   // 16-row form: the projection runs through mlp16_kernel's own ring (MODE 1), K-outer fragments
     const int P = h->inst->P;
     pack16_kouter(s, wc + De, De, D, qinco::round_up((De / 16) * (D / 16), P), I);
-    if (h->fold2) {   // second section: W_up[0] for Q_g = W_up[0] U_g, chained in the same launch
-      const float* up0 = w->up[(size_t)m * d.L];
-      if (!up0) return fail(QINCO_ERR_INVALID, "qinco_create: FFN weights[%d][0] null", m);
-      pack16_kouter(s, up0, d.Dh, De, qinco::round_up((d.Dh / 16) * (De / 16), P));
-    }
     s.resize(s.size() + (size_t)P * 256, 0.f);   // the ring prefetches P fragments past the end
   } else {
     for (int ob = 0; ob < De / 32; ++ob)
@@ -591,7 +586,6 @@ static int build_fold_tables(qinco_handle_s* h, const qinco_weights* w, int m) {
         Pt[(size_t)k * Dh + i] = a;
       }
     if ((rc = upload(h, &h->ptab[m], Pt.data(), Pt.size()))) return rc;
-    if (h->inst->var & 128) return 0;   // (16-row form: W_up[0] travels in the wx stream, above)
     std::vector<float> sq;
     sq.reserve((size_t)Dh * De);
     for (int ob = 0; ob < Dh / 32; ++ob)
@@ -979,7 +973,7 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
         const float* up = w->up[(size_t)m * d.L + l];
         const float* dn = w->down[(size_t)m * d.L + l];
         if (!up || !dn) return bail(fail(QINCO_ERR_INVALID, "qinco_create: FFN weights[%d][%d] null", m, l));
-        if (!(h->fold2 && l == 0)) pack16_kouter(s, up, d.Dh, d.De, sd.T_UP);
+        pack16_kouter(s, up, d.Dh, d.De, sd.T_UP);
         pack16_kouter(s, dn, d.De, d.Dh, sd.T_DOWN);
       }
       if (sd.PROJ) pack16_kouter(s, w->out_proj[m], d.D, d.De, sd.T_OUT);

@@ -627,8 +627,8 @@ def test_model_without_ffn_blocks(kw, split):
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [None, (48, 196), (48, 1220), (48, 1236), (48, 1268)],
-                         ids=["production", "tile16", "tile16_groups_of_8", "tile16_folded", "tile16_folded2"])
+@pytest.mark.parametrize("variant", [None, (48, 196), (48, 1220), (48, 1236)],
+                         ids=["production", "tile16", "tile16_groups_of_8", "tile16_folded"])
 def test_small_models_at_large_batches_are_exact_and_deterministic(variant):
     """Small models leave room for several workgroups per CU; the ring kernels must stay exact there (the 16-row kernel
     gave rare per-wave corruption with 3 workgroups per CU until its launch was made exclusive, csrc/mlp_inst.hip)."""

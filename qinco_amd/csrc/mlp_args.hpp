@@ -27,7 +27,7 @@ struct StreamDims {
 
 // fold = true: in_proj / bias / concat are not in the stream (the kernel starts from z = T[cid] + U[group], see
 // mlp_kernel.hpp FOLD).  tile = 32: mlp_kernel (32-feature blocks, 4 fragments per block pair); tile = 16:
-// mlp16_kernel (16-feature blocks, 1 fragment per block pair, never folded).
+// mlp16_kernel (16-feature blocks, 1 fragment per block pair, folded since round 3: FOLD only, no FOLD2).
 constexpr StreamDims stream_dims(int D, int DE, int DH, int P, bool fold = false, bool fold2 = false, int tile = 32) {
   StreamDims s{};
   const int fpp = tile == 32 ? 4 : 1;  // fragments (256 weights) per pair of blocks

@@ -11,7 +11,7 @@ cut -c1-260 $O/r03_late_bench_extra_q1_768.jsonl
 timeout 300 python scripts/exp_fold16.py 2>&1 | grep -v amdgpu.ids > $O/r03_exp_fold16.log; cat $O/r03_exp_fold16.log
 for s in 7 11 13 17; do
   c=48; [ $s = 7 ] && c=32; [ $s = 11 ] && c=40
-  timeout 900 python scripts/gpu_fuzz_geometry.py --seed $s --count $c --out $O/r03_fuzz_geometry_seed$s.jsonl 2>&1 | grep -v '"ok": true' | tail -4
+  timeout 900 python tests/sweeps/gpu_fuzz_geometry.py --seed $s --count $c --out $O/r03_fuzz_geometry_seed$s.jsonl 2>&1 | grep -v '"ok": true' | tail -4
 done
 cd /tmp
 prof() {  # name, rocprof args..., then the command after --

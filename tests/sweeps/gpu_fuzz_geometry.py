@@ -2,8 +2,8 @@
 """Randomised geometry / search-width sweep of the HIP path against the oracle (a one-off hunt for bugs the hand-picked test
 cases miss; the log goes to profiles/).
 
-    python scripts/gpu_fuzz_geometry.py --seed 7 --count 24 --prebuild     # build container: compile the on-demand instances
-    python scripts/gpu_fuzz_geometry.py --seed 7 --count 24 --out gpurun_out/fuzz.jsonl      # GPU box
+    python tests/sweeps/gpu_fuzz_geometry.py --seed 7 --count 24 --prebuild     # build container: compile the on-demand instances
+    python tests/sweeps/gpu_fuzz_geometry.py --seed 7 --count 24 --out gpurun_out/fuzz.jsonl      # GPU box
 
 Every configuration the reference's constructor accepts is fair game (qinco_base.py:229-260, utils.py:166-172): D not a
 multiple of 32, De = D or not, any hidden width, L from 0, M from 1, K other than 256 (VALU tables), A = 0 (QINCo1 mode) to
@@ -21,7 +21,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 

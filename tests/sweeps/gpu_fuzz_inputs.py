@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Adversarial INPUT rows through encode / decode against the oracle (the geometry sweep uses well-behaved Gaussian rows).
 
-    python scripts/gpu_fuzz_inputs.py --out gpurun_out/fuzz_inputs.jsonl         # GPU box
+    python tests/sweeps/gpu_fuzz_inputs.py --out gpurun_out/fuzz_inputs.jsonl         # GPU box
 
 Models: the golden cases' (tests/golden/cases.py: synthetic and reference-trained weights).  Rows per kind, all through the same
 bars as the tests (tie rule with oracle replay; reconstructions within 1e-5):
@@ -19,7 +19,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 sys.path.insert(0, str(ROOT / "tests" / "golden"))

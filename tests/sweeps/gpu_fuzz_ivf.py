@@ -2,7 +2,7 @@
 """Adversarial inputs for the IVF coarse assignment (csrc/ivf_f16_kernel.hpp: fp16 matrix-core filter, exact fp32 decision):
 the filter's error bound is claimed rigorous, so the arg-min must survive whatever the data looks like.
 
-    python scripts/gpu_fuzz_ivf.py --out gpurun_out/fuzz_ivf.jsonl         # GPU box
+    python tests/sweeps/gpu_fuzz_ivf.py --out gpurun_out/fuzz_ivf.jsonl         # GPU box
 
 Per case: a coarse codebook and vectors drawn to stress one thing -- near-duplicate centroids (distance gaps at rounding
 level), exact duplicates (ties: the lower id must win, like argmin), magnitudes from 1e-4 (fp16 subnormals) to 3e4 (the top
@@ -22,7 +22,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 
 KINDS = ["gauss", "near_dup", "exact_dup", "on_centroid", "heavy_tail", "outlier", "tiny", "huge", "beyond_fp16", "x_beyond_fp16", "bytes"]

@@ -2,11 +2,11 @@
 """Round-3 stress of the folded 16-row tile kernel on its production shape (QINCo1 at D = 768): distinct large batches, run-to-run
 repeats bit for bit, the rows that differ from the per-row-head instance (VAR 1220) judged by the oracle's tie rule, and scattered
 rows of every batch against the oracle.
-    python scripts/gpu_stress_fold16.py [--batches 6]"""
+    python tests/sweeps/gpu_stress_fold16.py [--batches 6]"""
 import argparse, sys, time
 from pathlib import Path
 import numpy as np, torch
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 from conftest import assert_only_near_ties, make_oracle
 from qinco_amd import QincoEngine, synth_state_dict, synth_vectors

@@ -928,7 +928,7 @@ def test_device_selftest_of_sort_and_selection_primitives():
     _lib.check(_lib.load().qinco_selftest())
 
 
-# ---- adversarial data (the sweeps of scripts/gpu_fuzz_inputs.py and scripts/gpu_fuzz_ivf.py, a compact cut of each) ---------------------
+# ---- adversarial data (the sweeps of tests/sweeps/gpu_fuzz_inputs.py and tests/sweeps/gpu_fuzz_ivf.py, a compact cut of each) ---------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["tiny_proj_beam", "trained_qinco2S", "trained_ivf_qinco2S"])
 def test_degenerate_and_extreme_rows_match_the_oracle(name):
@@ -936,7 +936,7 @@ def test_degenerate_and_extreme_rows_match_the_oracle(name):
     distance ~0 at the last step), 1e4 x and 1e-6 x the data's scale, one-hot spikes, the corners of the byte cube, the data
     mean itself, saw-teeth -- codes by the tie rule, reconstructions finite and within 1e-5."""
     import sys
-    sys.path.insert(0, str(ROOT / "scripts"))
+    sys.path.insert(0, str(ROOT / "tests" / "sweeps"))
     import gpu_fuzz_inputs as F
     from qinco_amd import QincoEngine
     cfg, sd = golden_model(name)
@@ -961,7 +961,7 @@ def test_ivf_filter_survives_adversarial_codebooks(kind):
     its flag hands the batch to the exact kernel), byte rows, 1000 centroids (not blocks of 32) -- the step-0 code is the arg-min of
     the reference's fp32 table (qinco_base.py:146-163) or within 2e-5 of it, and the lower id on exact duplicates."""
     import sys
-    sys.path.insert(0, str(ROOT / "scripts"))
+    sys.path.insert(0, str(ROOT / "tests" / "sweeps"))
     import gpu_fuzz_ivf as F
     from qinco_amd import QincoConfig, QincoEngine, synth_state_dict
     D, K, n = 128, 1000, 700

@@ -44,8 +44,12 @@ def draw(rs: np.random.RandomState) -> dict:
     ivf_K = int(rs.choice([64, 1000, 4096])) if rs.rand() < 0.2 else None
     n = int(rs.choice([1, 7, 65, 130, 200, 200, 333]))
     max_batch = int(rs.choice([64, 128, 4096]))
+    rebeam = None
+    if rs.rand() < 0.3 and A > 0:      # search widths changed after creation (the CLI override, utils.py:166-172): qinco_set_beam
+        rebeam = (int(rs.choice([1, 2, 4, 8, 16, min(32, K)])), int(rs.choice([1, 2, 4, 8, 16, 32])))
     u8 = bool(rs.rand() < 0.25)        # byte rows (bvecs datasets): the library converts them itself
-    return dict(cfg=dict(D=D, M=M, K=K, L=L, de=de, dh=dh, A=A, B=B, qinco1_mode=qinco1, ivf_K=ivf_K), n=n, max_batch=max_batch, u8=u8)
+    return dict(cfg=dict(D=D, M=M, K=K, L=L, de=de, dh=dh, A=A, B=B, qinco1_mode=qinco1, ivf_K=ivf_K), n=n, max_batch=max_batch, u8=u8,
+                rebeam=rebeam)
 
 
 def configs(seed: int, count: int):
@@ -108,6 +112,12 @@ def main() -> int:
                 assert x.dtype == np.uint8
             eng = QincoEngine(cfg, sd, max_batch=c["max_batch"])
             rec["describe"] = eng.describe()
+            if c.get("rebeam"):     # the handle was created for (A, B); it now searches with (A2, B2)
+                A2, B2 = c["rebeam"]
+                if cfg.ivf and B2 > cfg.K:
+                    B2 = cfg.K
+                eng.set_beam(A=A2, B=B2)
+                cfg = cfg.with_search(A=A2, B=B2)
             oracle = make_oracle(cfg, sd)
             want = oracle(x.astype(np.float32), step="encode").T
             got, xhat = eng.encode(x, return_xhat=True)

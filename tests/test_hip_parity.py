@@ -1030,3 +1030,39 @@ def test_handles_on_concurrent_host_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(K=512, A=16, B=4), dict(K=1024, A=32, B=2), dict(K=300, A=8, B=8), dict(K=512, A=0, B=1, qinco1_mode=True, de=None, dh=64),
+    dict(K=1024, A=0, B=2, qinco1_mode=True, de=None, dh=64), dict(K=512, A=8, B=4, ivf_K=2048), dict(K=700, A=700, B=3),
+], ids=lambda kw: f"K{kw['K']}_A{kw['A']}_B{kw['B']}" + ("_ivf" if kw.get("ivf_K") else ""))
+def test_codebooks_larger_than_256(kw):
+    """The reference takes any K (qinco_base.py:229-260: nn.Embedding(K, D)); the presets use 256 and so do the matrix-core table
+    kernels -- every other size runs the generic table / selection path (up to K = 1024).  Codes need int32 / int64 then (uint8 is
+    refused), and the oracle decides as always."""
+    from qinco_amd import QincoConfig, QincoEngine, synth_codes, synth_state_dict, synth_vectors
+    base = dict(D=32, M=3, L=2, de=64, dh=96, qinco1_mode=False)
+    base.update(kw)
+    cfg = QincoConfig(**base)
+    sd = synth_state_dict(cfg, 400 + cfg.K)
+    x = synth_vectors(cfg, sd, 260, seed=21)
+    eng = QincoEngine(cfg, sd, max_batch=128)
+    assert "table=valu" in eng.describe()
+    oracle = make_oracle(cfg, sd)
+    want = oracle(x, step="encode").T
+    got, xhat = eng.encode(x, return_xhat=True)
+    assert got.max() >= 256 and got.max() < max(cfg.K, cfg.ivf_K or 0)       # the codes really use the larger alphabet
+    nbad = assert_only_near_ties(oracle, x, got, want, NEAR_TIE, str(kw))
+    assert np.array_equal(eng.encode(x, code_dtype=np.int32), got.astype(np.int32))
+    with pytest.raises(ValueError):
+        eng.encode(x, code_dtype=np.uint8)
+    assert rel_err(eng.decode(want), oracle(want.T, step="decode")) < REL_TOL
+    rc = synth_codes(cfg, 64, seed=3).T.copy()
+    assert rel_err(eng.decode(rc), oracle(rc.T, step="decode")) < REL_TOL
+    bad = rc.copy()
+    bad[:, -1] = cfg.K
+    with pytest.raises(IndexError):
+        eng.decode(bad)
+    print(f"{kw}: {nbad} rows on ties")
+    eng.close()

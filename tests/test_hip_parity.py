@@ -1066,3 +1066,28 @@ def test_codebooks_larger_than_256(kw):
         eng.decode(bad)
     print(f"{kw}: {nbad} rows on ties")
     eng.close()
+
+
+@pytest.mark.gpu
+def test_long_codes_wide_beams_and_the_candidate_limit():
+    """M = 40 steps (the reference's longest preset is 32 bytes), a beam of 256 (B = K: every step-0 codeword survives), and the
+    stated limit: F x A candidates of a vector must fit the 160 KiB of LDS of beam_select -- beyond it the model is refused with a
+    reason, not run wrongly."""
+    from qinco_amd import QincoConfig, QincoEngine, synth_state_dict, synth_vectors
+    for kw, n in ((dict(M=40, A=4, B=2), 70), (dict(M=3, A=8, B=256), 40), (dict(M=4, A=256, B=32), 24)):
+        cfg = QincoConfig(D=32, K=256, L=1, de=64, dh=96, **kw)
+        sd = synth_state_dict(cfg, 77)
+        x = synth_vectors(cfg, sd, n, seed=5)
+        eng = QincoEngine(cfg, sd, max_batch=32)
+        oracle = make_oracle(cfg, sd)
+        want = oracle(x, step="encode").T
+        got = eng.encode(x)
+        assert got.shape == (n, cfg.M)
+        assert_only_near_ties(oracle, x, got, want, NEAR_TIE, str(kw))
+        assert rel_err(eng.decode(want), oracle(want.T, step="decode")) < REL_TOL
+        eng.close()
+    cfg = QincoConfig(D=32, M=3, K=256, L=1, de=64, dh=96, A=256, B=64)          # 16 384 candidates per vector
+    eng = QincoEngine(cfg, synth_state_dict(cfg, 78), max_batch=32)
+    with pytest.raises(NotImplementedError, match="candidates per vector"):
+        eng.encode(synth_vectors(cfg, synth_state_dict(cfg, 78), 8, seed=1))
+    eng.close()

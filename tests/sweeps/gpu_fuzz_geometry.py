@@ -6,7 +6,7 @@ cases miss; the log goes to profiles/).
     python tests/sweeps/gpu_fuzz_geometry.py --seed 7 --count 24 --out gpurun_out/fuzz.jsonl      # GPU box
 
 Every configuration the reference's constructor accepts is fair game (qinco_base.py:229-260, utils.py:166-172): D not a
-multiple of 32, De = D or not, any hidden width, L from 0, M from 1, K other than 256 (VALU tables), A = 0 (QINCo1 mode) to
+multiple of 32, De = D or not, any hidden width, L from 0, M from 1, K from 16 to 1024 (other than 256: VALU tables), A = 0 (QINCo1 mode) to
 A = K, B from 1 to beyond K, an IVF coarse step in front, a batch that is not a multiple of anything.  For each: encode codes
 by the tie rule of tests/conftest.py (a differing row must sit on a reference margin < 2e-5 AND be reproduced exactly by the
 oracle when nudged that way), tracked reconstructions and decode of random codes within 1e-5 relative.
@@ -29,7 +29,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 def draw(rs: np.random.RandomState) -> dict:
     D = int(rs.choice([8, 24, 40, 64, 96, 100, 128, 160, 200, 256, 300, 384, 512]))
     qinco1 = rs.rand() < 0.25
-    K = int(rs.choice([16, 64, 100, 256, 256, 256]))
+    K = int(rs.choice([16, 64, 100, 256, 256, 256, 300, 512, 1024]))
     if qinco1:
         de, A = None, 0
         B = int(rs.choice([1, 1, 4]))

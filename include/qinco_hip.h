@@ -94,7 +94,9 @@ QINCO_API int qinco_create(const qinco_desc* desc, const qinco_weights* weights,
  * from NaNs.  The library reads NO environment variables: every switch is an argument.
  * The other flags are diagnostics (A/B measurements, the race-detector tests): the exact fp32 IVF table without the fp16
  * filter; the VALU pre-selection table; decode through the folded encode instance; no cooperative table kernel; no fusion of
- * the pre-selection into the xproj launch on small launches. */
+ * the pre-selection into the xproj launch on small launches; no small-launch form of the fused MLP (csrc/mlp_small_kernel.hpp:
+ * launches below ~one 128-row workgroup per CU -- every decode call at the reference's batch sizes, greedy encode steps --
+ * otherwise run on workgroups of 16 * NT rows whose waves split the features, with the same products in the same order). */
 enum {
   QINCO_CREATE_SPLIT_F16 = 1,
   QINCO_CREATE_IVF_FP32 = 2,
@@ -102,7 +104,8 @@ enum {
   QINCO_CREATE_DECODE_FOLDED = 8,
   QINCO_CREATE_TABLE_NO_COOP = 16,
   QINCO_CREATE_SPLIT_NO_CALIBRATION = 32,  /* skip the create-time comparison with the fp32 instance (below) */
-  QINCO_CREATE_NO_PRESEL_FUSION = 64       /* diagnostics: pre-selection table and xproj as two launches at every launch size */
+  QINCO_CREATE_NO_PRESEL_FUSION = 64,      /* diagnostics: pre-selection table and xproj as two launches at every launch size */
+  QINCO_CREATE_NO_SMALL_LAUNCH = 128       /* diagnostics: the 128-rows-per-workgroup kernels at every launch size */
 };
 
 /* The split form checks itself.  (1) At create, unless QINCO_CREATE_SPLIT_NO_CALIBRATION: the model is also built as an fp32

@@ -30,6 +30,13 @@ def shapes() -> list[tuple[int, int, int, int, int]]:
             for m in re.finditer(r"^QINCO_SHAPE\((\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", txt, re.M)]
 
 
+def small_shapes() -> list[tuple[int, int, int, int]]:
+    """(D, De, Dh, FOLD2) of the small-launch fused-MLP kernels (csrc/small_shapes.def, csrc/mlp_small_kernel.hpp)."""
+    txt = (CSRC / "small_shapes.def").read_text()
+    return [tuple(int(v) for v in m.groups())
+            for m in re.finditer(r"^QINCO_SMALL_SHAPE\((\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", txt, re.M)]
+
+
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -90,6 +97,9 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     for shape in shapes():
         o = OBJ / ("mlp_" + "_".join(map(str, shape)) + ".o")
         want(o, instance_cmd(cc, shape, o))
+    for d, de, dh, f2 in small_shapes():
+        o = OBJ / f"small_{d}_{de}_{dh}_{f2}.o"
+        want(o, [cc, *FLAGS, f"-DQD={d}", f"-DQDE={de}", f"-DQDH={dh}", f"-DQF2={f2}", "-c", str(CSRC / "mlp_small_inst.hip"), "-o", str(o)])
     # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs.  The table / filter kernels post-process every accumulator on the VALU
     # (arg-min, max, compare), which cannot read AGPRs: with AGPR accumulators the IVF filter spent 3 of 4 VALU instructions
     # on v_accvgpr_read / write (csrc/ivf_f16_kernel.hpp).  The fused-MLP instances are separate objects and keep their plan.
@@ -104,7 +114,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
         with cf.ThreadPoolExecutor(max_workers=jobs or min(len(tasks), os.cpu_count() or 4)) as ex:
             for f in [ex.submit(_compile, o, cmd) for o, cmd in tasks]:
                 f.result()
-    for stale in OBJ.glob("mlp_*.o"):
+    for stale in [*OBJ.glob("mlp_*.o"), *OBJ.glob("small_*.o")]:
         if stale not in objs:
             for suf in (".o", ".d", ".cmd"):
                 stale.with_suffix(suf).unlink(missing_ok=True)

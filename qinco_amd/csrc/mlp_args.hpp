@@ -13,6 +13,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+// Bumped by hand whenever the MEANING of an argument block or of a launcher changes without changing its size (instance_abi).
+constexpr int kInstanceAbiVersion = 2;
+
 // Fragment (1 KiB = 64 lanes x float4) counts of each section of the packed per-step weight stream.
 // Every section is padded to a multiple of the ring depth P so ring slots are compile-time constants.
 struct StreamDims {
@@ -112,9 +115,76 @@ struct IvfArgs {
   const int* only_if;     // nullptr, or: do nothing unless *only_if != 0
 };
 
+// ---- small-launch form of the fused MLP (mlp_small_kernel.hpp): a workgroup owns 16 * NT rows and its four waves split the
+// OUTPUT features of every GEMM; activations meet in LDS between the GEMMs.  16-feature blocks; within a block the features sit in
+// the order the 32-row kernel contracts them, so both kernels add the same products in the same order.
+// Lane group kg = lane >> 4, register r of a block <-> feature offset small_feat(r, kg) of the block.
+constexpr int small_feat(int r, int kg) { return 8 * (r >> 1) + 2 * (r & 1) + (kg >> 1) + 4 * (kg & 1); }
+// position p (0..15) of the contraction order <-> feature offset (p = 4 r + kg)
+constexpr int small_feat_at(int p) { return small_feat(p >> 2, p & 3); }
+
+// Fragments (1 KiB) per wave of each section of a step's small-form stream.  Wave w owns the output blocks 4 j + w; a section is
+// [input block][j] per wave, the four waves' fragments interleaved ((f * 4 + w) KiB), zero fragments where 4 j + w is past the end.
+struct SmallDims {
+  int NDB, NEB, NHB;   // 16-feature blocks
+  int NDW, NEW, NHW;   // output blocks per wave (ceil(N / 4))
+  bool PROJ, FOLD2;
+  int F_HX, F_HQ, F_UP, F_DOWN, F_OUT;
+  constexpr int head() const { return F_HX + (FOLD2 ? F_HQ : 0); }                       // the in-kernel head (decode)
+  constexpr long step(int L) const { return (long)head() + (long)L * (F_UP + F_DOWN) - (FOLD2 ? F_UP : 0) + F_OUT; }
+};
+constexpr SmallDims small_dims(int D, int DE, int DH, bool fold2) {
+  SmallDims s{};
+  s.NDB = D / 16;
+  s.NEB = DE / 16;
+  s.NHB = DH / 16;
+  s.NDW = (s.NDB + 3) / 4;
+  s.NEW = (s.NEB + 3) / 4;
+  s.NHW = (s.NHB + 3) / 4;
+  s.PROJ = D != DE;
+  s.FOLD2 = fold2;
+  s.F_HX = s.NDB * s.NEW;
+  s.F_HQ = s.NEB * s.NHW;
+  s.F_UP = s.NEB * s.NHW;
+  s.F_DOWN = s.NHB * s.NEW;
+  s.F_OUT = s.PROJ ? s.NEB * s.NDW : 0;
+  return s;
+}
+
+struct SmallStep {          // per QINCo step, in device memory
+  const float* ttab;        // (K, De)  T_k = z_k + W_cat[:, :De] z_k + b
+  const float* ptab;        // (K, Dh)  P_k = W_up[0] T_k   (FOLD2)
+  const float* codebook;    // (K, D)
+};
+
+struct SmallArgs {
+  const f32x4* wstream;     // small-form stream, positioned at the first fragment this launch consumes
+  const SmallStep* steps;   // indexed by step m
+  int m_first, m_count;     // steps this launch runs: decode 1 .. M-1, an encode step: one
+  int L;
+  int add_c;
+  long R;                   // rows
+  // ---- one encode step: head from the tables and the per-group projections (xproj / presel_xproj kernels)
+  const int* cand_ids;      // (R) or nullptr -> row % A
+  int A, F;
+  const float* xhat;        // (R / A, D)
+  const float* x;           // (R / A / F, D)
+  const float* uproj;       // (R / A, De)
+  const float* qproj;       // (R / A, Dh)
+  float* cand_out;          // (R, D)
+  float* dist_out;          // (R)
+  // ---- decode, every step in one launch: the head is computed in the kernel (same association: T[code] + W_x xhat)
+  const int* codes_t;       // (M, R) step-major codes
+  const float* codebook0;   // step 0: xhat = codebook0[code]
+  float* out;               // (R, Duser) de-normalised reconstruction
+  const float* mean;        // nullptr: leave normalised
+  float std_;
+  int Duser;
+};
+
 // Source-version check between the library and a module built on demand: the sizes of the argument blocks they exchange.
 constexpr int instance_abi() {
-  return (int)((sizeof(MlpArgs) << 20) | (sizeof(XprojArgs) << 8) | sizeof(IvfArgs));
+  return (int)((sizeof(MlpArgs) << 20) | (sizeof(XprojArgs) << 8) | sizeof(IvfArgs)) ^ (int)((sizeof(TableArgs) << 12) | (sizeof(SmallArgs) << 4)) ^ (kInstanceAbiVersion << 26);
 }
 static_assert(sizeof(MlpArgs) < 2048 && sizeof(XprojArgs) < 4096 && sizeof(IvfArgs) < 256, "instance_abi packing");
 

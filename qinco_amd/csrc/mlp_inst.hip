@@ -52,6 +52,12 @@ hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::Mlp
 #ifdef QINCO_INSTANCE_MODULE
 #include "ivf_kernel.hpp"
 #include "table_kernel.hpp"
+#if (QVAR & 16) && !(QVAR & 512)   // a folded fp32 instance: the module also brings the small-launch form of its shape
+#define QF2 ((QVAR & 32) ? 1 : 0)
+#define QINCO_MODULE_HAS_SMALL 1
+#define QINCO_SMALL_FN_NAME qinco_module_small_launch
+#include "mlp_small_inst.hip"
+#endif
 extern "C" __attribute__((visibility("hidden"))) hipError_t qinco_module_ivf_launch(const qinco::IvfArgs* a, hipStream_t stream) {
   if (a->N <= 0) return hipSuccess;
   return qinco::launch_ivf_assign_kernel<QD>(*a, stream);
@@ -61,7 +67,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t qinco_module_table_l
   return qinco::launch_table_kernels<QD>(*a, stream);
 }
 // Built on demand as a shared object of its own (qinco_amd.build.ensure_instance) and registered with qinco_load_instance:
-// v = {D, De, Dh, P, VAR, 0}, fns = {mlp launcher, xproj launcher, table launcher (K = 256 pre-selection for this D), IVF coarse assignment for this D}; returns instance_abi() (the sizes of the argument blocks) as the
+// v = {D, De, Dh, P, VAR, 0}, fns = {mlp launcher, xproj launcher, table launcher (K = 256 pre-selection for this D), IVF coarse assignment for this D,
+// small-launch form or nullptr}; returns instance_abi() (the sizes of the argument blocks) as the
 // source-version check (a module built against another csrc/mlp_args.hpp must not be launched).
 extern "C" hipError_t QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::XprojArgs* a, hipStream_t stream);
 extern "C" __attribute__((visibility("default"))) int qinco_instance_info(int* v, void** fns) {
@@ -74,6 +81,9 @@ extern "C" __attribute__((visibility("default"))) int qinco_instance_info(int* v
   fns[1] = reinterpret_cast<void*>(&QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR));
   fns[2] = reinterpret_cast<void*>(&qinco_module_table_launch);
   fns[3] = reinterpret_cast<void*>(&qinco_module_ivf_launch);
+#ifdef QINCO_MODULE_HAS_SMALL
+  fns[4] = reinterpret_cast<void*>(&qinco_module_small_launch);
+#endif
   return qinco::instance_abi();
 }
 #endif

@@ -34,13 +34,37 @@ using namespace qinco;
 #include "shapes.def"
 #undef QINCO_SHAPE
 
+#define QINCO_SMALL_SHAPE(D, DE, DH, F2) \
+  extern "C" hipError_t qinco_small_launch_##D##_##DE##_##DH##_##F2(const qinco::SmallArgs*, int, int, hipStream_t);
+#include "small_shapes.def"
+#undef QINCO_SMALL_SHAPE
+
 namespace qinco {
 static const MlpInstance g_instances[] = {
 #define QINCO_SHAPE(d, de, dh, p, var) \
-  {d, de, dh, p, var, &qinco_mlp_launch_##d##_##de##_##dh##_##p##_##var, &qinco_xproj_launch_##d##_##de##_##dh##_##p##_##var, nullptr, nullptr},
+  {d, de, dh, p, var, &qinco_mlp_launch_##d##_##de##_##dh##_##p##_##var, &qinco_xproj_launch_##d##_##de##_##dh##_##p##_##var, nullptr, nullptr, nullptr},
 #include "shapes.def"
 #undef QINCO_SHAPE
 };
+
+// the small-launch form (mlp_small_kernel.hpp) of the compiled-in shapes
+struct SmallInstance {
+  int D, De, Dh, fold2;
+  small_launch_fn fn;
+};
+static const SmallInstance g_small[] = {
+#define QINCO_SMALL_SHAPE(d, de, dh, f2) {d, de, dh, f2, &qinco_small_launch_##d##_##de##_##dh##_##f2},
+#include "small_shapes.def"
+#undef QINCO_SMALL_SHAPE
+};
+// ... of an fp32 instance with the folded head (the small form starts from z = T[codeword] + U[group] like it)
+static small_launch_fn find_small_launcher(const MlpInstance* i) {
+  if (!i || !(i->var & 16) || (i->var & 512)) return nullptr;
+  if (i->small) return i->small;
+  for (const SmallInstance& s : g_small)
+    if (s.D == i->D && s.De == i->De && s.Dh == i->Dh && s.fold2 == ((i->var & 32) ? 1 : 0)) return s.fn;
+  return nullptr;
+}
 
 // Instances built on demand for geometries shapes.def does not list (qinco_load_instance): each lives in a shared object of
 // its own -- one translation unit of csrc/mlp_inst.hip with its shape as -D flags -- and is never unloaded.  A deque: element
@@ -103,6 +127,7 @@ struct qinco_handle_s {
   qinco_desc d{};      // the geometry the kernels run (D, De, Dh padded to multiples of 32; L >= 1)
   qinco_desc user{};   // the model's own hyper-parameters: I/O row widths and FLOP accounting
   int device = 0;
+  int num_cu = 256;
   int A = 0, B = 1;  // active search widths
   const MlpInstance* inst = nullptr;
   StreamDims sd{};
@@ -126,6 +151,12 @@ struct qinco_handle_s {
   const MlpInstance* dec_inst = nullptr;
   StreamDims dec_sd{};
   std::vector<f32x4*> dec_wstream;
+  // small-launch form (mlp_small_kernel.hpp): its weight stream (every step, contiguous), per-step table pointers, largest NT
+  small_launch_fn small = nullptr;
+  SmallDims ssd{};
+  f32x4* small_stream = nullptr;
+  SmallStep* small_steps = nullptr;
+  int small_max_nt[2] = {0, 0};   // [encode step, decode]
   int* kvals = nullptr;
   int* err_flag = nullptr;
   unsigned long long* split_stats = nullptr;   // split form: [activations sampled, fp16 lo parts subnormal] (mlp_split_kernel.hpp)
@@ -297,6 +328,28 @@ static void pack16_bias(std::vector<float>& s, const float* b, int O, int T) {
       for (int r = 0; r < 4; ++r) s[base + l * 4 + r] = b[ob * 16 + 4 * (l >> 4) + r];
   }
   pad_to(s, start, T);
+}
+
+// Small-launch form (mlp_small_kernel.hpp): 16-feature blocks whose features sit in the 32-row kernel's contraction order.
+// Fragment (ob, ib) = the A operands of the 4 MFMAs (v_mfma_f32_16x16x4_f32) of one 16 x 16 weight block: lane l, component e =
+// W[16 ob + small_feat(m & 3, m >> 2)][16 ib + small_feat_at(4 e + (l >> 4))] with m = l & 15 -- MFMA output row m = 4 kg + r lands in
+// lane group kg, register r, which is where the next layer's B operand wants feature small_feat(r, kg).  A section is, per wave w,
+// [input block][j] with output block 4 j + w; the four waves' fragments are interleaved, blocks past the end are zero fragments.
+static void pack_small_section(std::vector<float>& s, const float* W, int O, int I, int ld) {
+  const int NOB = O / 16, NIB = I / 16, NOW = (NOB + 3) / 4;
+  for (int ib = 0; ib < NIB; ++ib)
+    for (int j = 0; j < NOW; ++j)
+      for (int w = 0; w < 4; ++w) {
+        const int ob = 4 * j + w;
+        const size_t base = s.size();
+        s.resize(base + 256, 0.f);
+        if (ob >= NOB) continue;
+        for (int l = 0; l < 64; ++l) {
+          const int m = l & 15, kga = l >> 4;
+          const float* wr = W + (size_t)(16 * ob + small_feat(m & 3, m >> 2)) * ld + 16 * ib;
+          for (int e = 0; e < 4; ++e) s[base + l * 4 + e] = wr[small_feat_at(4 * e + kga)];
+        }
+      }
 }
 
 // Split-fp16 form (mlp_split_kernel.hpp): fragment = the A operand of one v_mfma_f32_32x32x16_f16, 32 output features x 16
@@ -656,7 +709,7 @@ extern "C" int qinco_load_instance(const char* path) {
                                    "with -DQINCO_INSTANCE_MODULE?)", path);
   }
   int32_t v[6] = {0, 0, 0, 0, 0, 0};
-  void* fns[4] = {nullptr, nullptr, nullptr, nullptr};
+  void* fns[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   const int abi = info(v, fns), want_abi = instance_abi();
   if (abi != want_abi || !fns[0] || !fns[1]) {
     dlclose(so);
@@ -667,7 +720,7 @@ extern "C" int qinco_load_instance(const char* path) {
     if (i.D == v[0] && i.De == v[1] && i.Dh == v[2] && i.P == v[3] && i.var == v[4]) return QINCO_OK;   // already there
   g_loaded.push_back(MlpInstance{v[0], v[1], v[2], v[3], v[4], reinterpret_cast<mlp_launch_fn>(fns[0]),
                                  reinterpret_cast<xproj_launch_fn>(fns[1]), reinterpret_cast<table_launch_fn>(fns[2]),
-                                 reinterpret_cast<ivf_launch_fn>(fns[3])});
+                                 reinterpret_cast<ivf_launch_fn>(fns[3]), reinterpret_cast<small_launch_fn>(fns[4])});
   return QINCO_OK;
 }
 
@@ -741,7 +794,8 @@ struct CreateOpts {
   long table_coop_max = -1;
 };
 static const int kCreateFlagMask = QINCO_CREATE_SPLIT_F16 | QINCO_CREATE_IVF_FP32 | QINCO_CREATE_TABLE_VALU | QINCO_CREATE_DECODE_FOLDED |
-                                   QINCO_CREATE_TABLE_NO_COOP | QINCO_CREATE_SPLIT_NO_CALIBRATION | QINCO_CREATE_NO_PRESEL_FUSION;
+                                   QINCO_CREATE_TABLE_NO_COOP | QINCO_CREATE_SPLIT_NO_CALIBRATION | QINCO_CREATE_NO_PRESEL_FUSION |
+                                   QINCO_CREATE_NO_SMALL_LAUNCH;
 
 static void env_opts(CreateOpts& o) {
 #ifdef QINCO_EXPERIMENT
@@ -751,6 +805,7 @@ static void env_opts(CreateOpts& o) {
   if (getenv("QINCO_DECODE_FOLDED")) o.flags |= QINCO_CREATE_DECODE_FOLDED;
   if (getenv("QINCO_TABLE_NO_COOP")) o.flags |= QINCO_CREATE_TABLE_NO_COOP;
   if (getenv("QINCO_NO_PRESEL_FUSION")) o.flags |= QINCO_CREATE_NO_PRESEL_FUSION;
+  if (getenv("QINCO_NO_SMALL_LAUNCH")) o.flags |= QINCO_CREATE_NO_SMALL_LAUNCH;
   if (const char* e = getenv("QINCO_TABLE_COOP_MAX")) o.table_coop_max = atol(e);
   if (const char* e = getenv("QINCO_MLP_VARIANT")) sscanf(e, "%d,%d", &o.mlp_P, &o.mlp_var);
 #else
@@ -901,6 +956,10 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
     return code;
   };
   if (hipGetDevice(&h->device) != hipSuccess) return bail(fail(QINCO_ERR_HIP, "hipGetDevice failed (no HIP device?)"));
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cu = cus;
+  }
   if (h->split16) {   // the split-form kernel of the 384-wide shapes uses all 160 KiB of a gfx950 CU's LDS (ring + parked z')
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) != hipSuccess || lds < 160 * 1024)
@@ -1045,6 +1104,40 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
       float* dt = nullptr;
       if ((rc = upload(h, &dt, t.data(), t.size()))) return bail(rc);
       h->dec_wstream[m] = reinterpret_cast<f32x4*>(dt);
+    }
+  }
+  // ---- small-launch form: one contiguous stream over the steps 1 .. M-1 (decode walks through all of them in one launch) ----
+  if (d.M > 1 && !(create_flags & QINCO_CREATE_NO_SMALL_LAUNCH) && !h->split16) {
+    if (small_launch_fn sf = find_small_launcher(fn)) {
+      h->small_max_nt[0] = (int)sf(nullptr, 0, 0, nullptr);
+      h->small_max_nt[1] = (int)sf(nullptr, 1, 0, nullptr);
+    if (h->small_max_nt[0] > 0 || h->small_max_nt[1] > 0) {
+      h->small = sf;
+      h->ssd = small_dims(d.D, d.De, d.Dh, h->fold2);
+      const SmallDims& S = h->ssd;
+      std::vector<float> t;
+      t.reserve((size_t)((d.M - 1) * S.step(d.L) + 64) * 4 * 256);
+      for (int m = 1; m < d.M; ++m) {
+        const size_t start = t.size();
+        pack_small_section(t, w->cat_w[m] + d.De, d.De, d.D, d.De + d.D);
+        if (h->fold2) pack_small_section(t, w->up[(size_t)m * d.L], d.Dh, d.De, d.De);
+        for (int l = 0; l < d.L; ++l) {
+          if (!(h->fold2 && l == 0)) pack_small_section(t, w->up[(size_t)m * d.L + l], d.Dh, d.De, d.De);
+          pack_small_section(t, w->down[(size_t)m * d.L + l], d.De, d.Dh, d.Dh);
+        }
+        if (S.PROJ) pack_small_section(t, w->out_proj[m], d.D, d.De, d.De);
+        if ((long)((t.size() - start) / 1024) != S.step(d.L)) return bail(fail(QINCO_ERR_INVALID, "internal: small-form stream size mismatch"));
+      }
+      t.resize(t.size() + (size_t)64 * 4 * 256, 0.f);   // the rings prefetch up to PW <= 64 fragments per wave past the end
+      float* dt = nullptr;
+      if ((rc = upload(h, &dt, t.data(), t.size()))) return bail(rc);
+      h->small_stream = reinterpret_cast<f32x4*>(dt);
+      std::vector<SmallStep> ss(d.M);
+      for (int m = 1; m < d.M; ++m) ss[m] = SmallStep{h->ttab[m], h->ptab[m], h->codebook[m]};
+      if ((rc = dev_alloc(h, &h->small_steps, (size_t)d.M))) return bail(rc);
+      if (hipMemcpy(h->small_steps, ss.data(), ss.size() * sizeof(SmallStep), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(QINCO_ERR_HIP, "hipMemcpy(small_steps) failed"));
+    }
     }
   }
   if ((rc = ensure_scratch(h))) return bail(rc);
@@ -1201,6 +1294,33 @@ static bool presel_fused(const qinco_handle_s* h, long G) {
          mfma_table_ok(h->d, h->inst) && presel_coop_ok(h->d.De, h->d.Dh, h->inst->var) && !h->no_presel_fusion;
 }
 
+// Which form serves a launch of R rows: NT (row tiles of 16 per workgroup) of the small-launch form, or 0 = the 128-row kernels.
+// Cost in "one 16-row tile on one CU": a launch takes ceil(workgroups / CUs) rounds; a round of the 128-row kernel costs 8 tiles, a
+// round of the small form NT tiles plus its per-workgroup fixed part (ring prologue, head gathers, barriers).  Larger NT = fewer weight
+// bytes per row, so ties go to the larger NT.
+static int small_nt(const qinco_handle_s* h, long R, bool dec) {
+  const int mx = h->small ? h->small_max_nt[dec ? 1 : 0] : 0;
+  if (mx <= 0 || R <= 0) return 0;
+  const long cus = h->num_cu;
+  auto rounds = [&](long wgs) { return (double)((wgs + cus - 1) / cus); };
+  double best_cost = rounds((R + 127) / 128) * 8.0 * 0.97;
+  int best = 0;
+  for (int nt = mx; nt >= 1; --nt) {
+    const double c = rounds((R + 16 * nt - 1) / (16 * nt)) * (nt + 0.35);
+    if (c < best_cost - 1e-9) {
+      best_cost = c;
+      best = nt;
+    }
+  }
+  return best;
+}
+
+// position of step m's fragments in the small-form stream (f32x4 units); body = past the in-kernel head sections
+static const f32x4* small_stream_at(const qinco_handle_s* h, int m, bool body) {
+  const long frags = (long)(m - 1) * h->ssd.step(h->d.L) + (body ? h->ssd.head() : 0);
+  return h->small_stream + frags * 4 * 64;
+}
+
 static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool decode = false, const PreselJob* pj = nullptr) {
   const bool unfolded = decode && h->dec_inst;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1257,7 +1377,29 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
     a.timeline = h->tl;
   }
 #endif
-  HIP_TRY((unfolded ? h->dec_inst : h->inst)->fn(&a, st));
+  const int nt = decode ? 0 : small_nt(h, a.R, false);
+  if (nt > 0) {   // small launch: workgroups of 16 nt rows, same head (T + U, relu(P + Q)) and the same products in the same order
+    SmallArgs sa{};
+    sa.wstream = small_stream_at(h, m, true);
+    sa.steps = h->small_steps;
+    sa.m_first = m;
+    sa.m_count = 1;
+    sa.L = a.L;
+    sa.add_c = a.add_c;
+    sa.R = a.R;
+    sa.cand_ids = a.cand_ids;
+    sa.A = a.A;
+    sa.F = a.F;
+    sa.xhat = a.xhat;
+    sa.x = a.x;
+    sa.uproj = a.uproj;
+    sa.qproj = a.qproj;
+    sa.cand_out = a.cand_out;
+    sa.dist_out = a.dist_out;
+    HIP_TRY(h->small(&sa, 0, nt, st));
+  } else {
+    HIP_TRY((unfolded ? h->dec_inst : h->inst)->fn(&a, st));
+  }
   if (h->prof) {
     HIP_TRY(hipEventRecord(e1, st));
     h->prof_flops += (double)a.R * mlp_flops_per_row(h);
@@ -1510,6 +1652,43 @@ static int decode_chunk(qinco_handle_s* h, const void* codes, int code_dtype, in
   hipLaunchKernelGGL(import_codes_kernel, dim3(ew_grid(n * M)), dim3(256), 0, st, codes, code_dtype, (long)n, M, h->kvals,
                      h->codes_t, h->err_flag);
   HIP_TRY(hipGetLastError());
+  if (const int nt = M > 1 ? small_nt(h, n, true) : 0) {
+    // small call (the reference decodes 1024 / 12 288 rows per call): every step of a row tile in ONE launch of the small form --
+    // xhat stays in the workgroup, the head is computed in the kernel in the folded association (T[code] + W_x xhat)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+      if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t a0, a1;
+        HIP_TRY(hipEventCreate(&a0));
+        HIP_TRY(hipEventCreate(&a1));
+        h->ev_pool.emplace_back(a0, a1);
+      }
+      e0 = h->ev_pool[h->ev_used].first;
+      e1 = h->ev_pool[h->ev_used].second;
+      h->ev_used++;
+      HIP_TRY(hipEventRecord(e0, st));
+    }
+    SmallArgs sa{};
+    sa.wstream = small_stream_at(h, 1, false);
+    sa.steps = h->small_steps;
+    sa.m_first = 1;
+    sa.m_count = M - 1;
+    sa.L = d.L;
+    sa.add_c = d.qinco1_mode ? 0 : 1;
+    sa.R = n;
+    sa.codes_t = h->codes_t;
+    sa.codebook0 = h->codebook[0];
+    sa.out = out;
+    sa.mean = (flags & QINCO_FLAG_NORMALISED) ? nullptr : h->mean;
+    sa.std_ = h->std_;
+    sa.Duser = h->user.D;
+    HIP_TRY(h->small(&sa, 1, nt, st));
+    if (h->prof) {
+      HIP_TRY(hipEventRecord(e1, st));
+      h->prof_flops += (double)n * (M - 1) * mlp_flops_per_row(h);
+    }
+    return 0;
+  }
   int cur = 0;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(n * (D / 4))), dim3(256), 0, st, h->codebook[0], h->codes_t, (long)n, D,
                      h->dxhat[cur], (int*)nullptr, M);

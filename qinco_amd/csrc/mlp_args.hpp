@@ -115,19 +115,21 @@ struct IvfArgs {
   const int* only_if;     // nullptr, or: do nothing unless *only_if != 0
 };
 
-// ---- small-launch form of the fused MLP (mlp_small_kernel.hpp): a workgroup owns 16 * NT rows and its four waves split the
+// ---- small-launch form of the fused MLP (mlp_small_kernel.hpp): a workgroup owns 16 * NT rows and its kSmallWaves waves split the
 // OUTPUT features of every GEMM; activations meet in LDS between the GEMMs.  16-feature blocks; within a block the features sit in
 // the order the 32-row kernel contracts them, so both kernels add the same products in the same order.
 // Lane group kg = lane >> 4, register r of a block <-> feature offset small_feat(r, kg) of the block.
+constexpr int kSmallWaves = 8;   // two waves per SIMD: one wave's ring / address bookkeeping issues under the other's MFMAs
 constexpr int small_feat(int r, int kg) { return 8 * (r >> 1) + 2 * (r & 1) + (kg >> 1) + 4 * (kg & 1); }
 // position p (0..15) of the contraction order <-> feature offset (p = 4 r + kg)
 constexpr int small_feat_at(int p) { return small_feat(p >> 2, p & 3); }
 
-// Fragments (1 KiB) per wave of each section of a step's small-form stream.  Wave w owns the output blocks 4 j + w; a section is
-// [input block][j] per wave, the four waves' fragments interleaved ((f * 4 + w) KiB), zero fragments where 4 j + w is past the end.
+// Fragments (1 KiB) per wave of each section of a step's small-form stream.  Wave w owns the output blocks NW j + w (NW =
+// kSmallWaves); a section is [input block][j] per wave, the waves' fragments interleaved ((f * NW + w) KiB), zero fragments where
+// NW j + w is past the end.
 struct SmallDims {
   int NDB, NEB, NHB;   // 16-feature blocks
-  int NDW, NEW, NHW;   // output blocks per wave (ceil(N / 4))
+  int NDW, NEW, NHW;   // output blocks per wave (ceil(N / kSmallWaves))
   bool PROJ, FOLD2;
   int F_HX, F_HQ, F_UP, F_DOWN, F_OUT;
   constexpr int head() const { return F_HX + (FOLD2 ? F_HQ : 0); }                       // the in-kernel head (decode)
@@ -138,9 +140,9 @@ constexpr SmallDims small_dims(int D, int DE, int DH, bool fold2) {
   s.NDB = D / 16;
   s.NEB = DE / 16;
   s.NHB = DH / 16;
-  s.NDW = (s.NDB + 3) / 4;
-  s.NEW = (s.NEB + 3) / 4;
-  s.NHW = (s.NHB + 3) / 4;
+  s.NDW = (s.NDB + kSmallWaves - 1) / kSmallWaves;
+  s.NEW = (s.NEB + kSmallWaves - 1) / kSmallWaves;
+  s.NHW = (s.NHB + kSmallWaves - 1) / kSmallWaves;
   s.PROJ = D != DE;
   s.FOLD2 = fold2;
   s.F_HX = s.NDB * s.NEW;
@@ -151,7 +153,8 @@ constexpr SmallDims small_dims(int D, int DE, int DH, bool fold2) {
   return s;
 }
 
-struct SmallStep {          // per QINCo step, in device memory
+struct SmallStep {          // per QINCo step, in device memory; every table in BLOCK LAYOUT: entry 4 kg + r of a 16-block is feature
+                            // small_feat(r, kg), so the four registers of a lane (group kg) are one 16-byte load
   const float* ttab;        // (K, De)  T_k = z_k + W_cat[:, :De] z_k + b
   const float* ptab;        // (K, Dh)  P_k = W_up[0] T_k   (FOLD2)
   const float* codebook;    // (K, D)
@@ -180,6 +183,9 @@ struct SmallArgs {
   const float* mean;        // nullptr: leave normalised
   float std_;
   int Duser;
+#ifdef QINCO_TIMELINE       // experiment builds only (scripts/ubench/small_timeline.hip): cycle stamps of every wave
+  unsigned long long* timeline;   // (workgroups, kSmallWaves, 64)
+#endif
 };
 
 // Source-version check between the library and a module built on demand: the sizes of the argument blocks they exchange.

@@ -24,7 +24,7 @@ hipError_t launch_small(const qinco::SmallArgs& a, hipStream_t st) {
       raised = true;
     }
     const unsigned grid = (unsigned)((a.R + 16 * NT - 1) / (16 * NT));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), PL.lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * qinco::kSmallWaves), PL.lds_bytes, st, a);
     return hipGetLastError();
   }
 }

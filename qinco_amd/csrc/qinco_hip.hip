@@ -139,6 +139,7 @@ struct qinco_handle_s {
   // FOLD: per-codeword head table T (K, De) and the xhat half of the concat weight as fragments, per step
   bool fold = false, fold2 = false;
   std::vector<float*> ttab, ptab;            // T (K, De);  FOLD2: P = W_up[0] T (K, Dh)
+  std::vector<float*> ttab_s, ptab_s, cb_s;  // block-layout copies of T, P and the codebooks for the small-launch form (upload_block_layout)
   std::vector<f32x4*> wx_stream, wq_stream;  // W_cat[:, De:] and (FOLD2) W_up[0] as fragments for xproj_kernel
   float* uproj = nullptr;      // (max_batch * B, De [+ Dh]) scratch: U_g = W_cat[:, De:] xhat_g  [then Q_g = W_up[0] U_g]
   float* duproj = nullptr;     // decode counterpart (dec_cap, De [+ Dh])
@@ -153,6 +154,7 @@ struct qinco_handle_s {
   std::vector<f32x4*> dec_wstream;
   // small-launch form (mlp_small_kernel.hpp): its weight stream (every step, contiguous), per-step table pointers, largest NT
   small_launch_fn small = nullptr;
+  bool want_small = false;   // decided before the per-step tables are built (they get block-layout copies)
   SmallDims ssd{};
   f32x4* small_stream = nullptr;
   SmallStep* small_steps = nullptr;
@@ -334,13 +336,14 @@ static void pack16_bias(std::vector<float>& s, const float* b, int O, int T) {
 // Fragment (ob, ib) = the A operands of the 4 MFMAs (v_mfma_f32_16x16x4_f32) of one 16 x 16 weight block: lane l, component e =
 // W[16 ob + small_feat(m & 3, m >> 2)][16 ib + small_feat_at(4 e + (l >> 4))] with m = l & 15 -- MFMA output row m = 4 kg + r lands in
 // lane group kg, register r, which is where the next layer's B operand wants feature small_feat(r, kg).  A section is, per wave w,
-// [input block][j] with output block 4 j + w; the four waves' fragments are interleaved, blocks past the end are zero fragments.
+// [input block][j] with output block NW j + w; the NW = kSmallWaves waves' fragments are interleaved, blocks past the end are zero
+// fragments.
 static void pack_small_section(std::vector<float>& s, const float* W, int O, int I, int ld) {
-  const int NOB = O / 16, NIB = I / 16, NOW = (NOB + 3) / 4;
+  const int NW = kSmallWaves, NOB = O / 16, NIB = I / 16, NOW = (NOB + NW - 1) / NW;
   for (int ib = 0; ib < NIB; ++ib)
     for (int j = 0; j < NOW; ++j)
-      for (int w = 0; w < 4; ++w) {
-        const int ob = 4 * j + w;
+      for (int w = 0; w < NW; ++w) {
+        const int ob = NW * j + w;
         const size_t base = s.size();
         s.resize(base + 256, 0.f);
         if (ob >= NOB) continue;
@@ -409,6 +412,18 @@ static int upload(qinco_handle_s* h, float** dst, const float* src, size_t count
   if (rc) return rc;
   HIP_TRY(hipMemcpy(*dst, src, count * sizeof(float), hipMemcpyHostToDevice));
   return 0;
+}
+
+// A (rows, W) table with the features of every 16-block grouped by the lane group that holds them in the small-launch form
+// (mlp_args.hpp small_feat): entry 4 kg + r of a block is feature small_feat(r, kg), so lane group kg of mlp_small_kernel finds its
+// four registers of a block in ONE 16-byte load.
+static int upload_block_layout(qinco_handle_s* h, const float* src, int rows, int W, float** dst) {
+  std::vector<float> t((size_t)rows * W);
+  for (int row = 0; row < rows; ++row)
+    for (int b = 0; b < W / 16; ++b)
+      for (int kg = 0; kg < 4; ++kg)
+        for (int r = 0; r < 4; ++r) t[(size_t)row * W + 16 * b + 4 * kg + r] = src[(size_t)row * W + 16 * b + small_feat(r, kg)];
+  return upload(h, dst, t.data(), t.size());
 }
 
 // codebook (K, D) in MFMA fragment order: (block of 32 codewords, feature block, q) -> 1 KiB
@@ -590,6 +605,8 @@ static int build_fold_tables(qinco_handle_s* h, const qinco_weights* w, int m) {
   }
   int rc = upload(h, &h->ttab[m], T.data(), T.size());
   if (rc) return rc;
+  if (h->want_small && ((rc = upload_block_layout(h, T.data(), K, De, &h->ttab_s[m])) || (rc = upload_block_layout(h, cb, K, D, &h->cb_s[m]))))
+    return rc;
   std::vector<float> s;
   s.reserve((size_t)De * D);
   if (h->inst->var & 128) {   // 16-row form: the projection runs through mlp16_kernel's own ring (MODE 1), K-outer fragments
@@ -639,6 +656,7 @@ static int build_fold_tables(qinco_handle_s* h, const qinco_weights* w, int m) {
         Pt[(size_t)k * Dh + i] = a;
       }
     if ((rc = upload(h, &h->ptab[m], Pt.data(), Pt.size()))) return rc;
+    if (h->want_small && (rc = upload_block_layout(h, Pt.data(), K, Dh, &h->ptab_s[m]))) return rc;
     std::vector<float> sq;
     sq.reserve((size_t)Dh * De);
     for (int ob = 0; ob < Dh / 32; ++ob)
@@ -938,6 +956,9 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   h->fold2 = fn && (fn->var & 32);
   h->split16 = fn && (fn->var & 512);
   const bool tile16 = fn && (fn->var & 128);
+  small_launch_fn small_fn = nullptr;
+  if (d.M > 1 && !(create_flags & QINCO_CREATE_NO_SMALL_LAUNCH) && !h->split16) small_fn = find_small_launcher(fn);
+  h->want_small = small_fn != nullptr;
   h->sd = stream_dims(d.D, d.De, d.Dh, kRing, h->fold, h->fold2, tile16 ? 16 : 32);
   // Decode through an un-folded twin of the instance: only where that is faster -- the two-workgroups-per-CU (short-MLP) shapes
   // (qinco2-S: 57.4 M vec/s against 54.5 M through the folded kernel).  On the 384-wide shapes the folded kernel wins once the
@@ -977,6 +998,9 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   h->sub_stream.assign(d.M, nullptr);
   h->ttab.assign(d.M, nullptr);
   h->ptab.assign(d.M, nullptr);
+  h->ttab_s.assign(d.M, nullptr);
+  h->ptab_s.assign(d.M, nullptr);
+  h->cb_s.assign(d.M, nullptr);
   h->wx_stream.assign(d.M, nullptr);
   h->wq_stream.assign(d.M, nullptr);
   h->smul.assign(d.M, nullptr);
@@ -1107,8 +1131,8 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
     }
   }
   // ---- small-launch form: one contiguous stream over the steps 1 .. M-1 (decode walks through all of them in one launch) ----
-  if (d.M > 1 && !(create_flags & QINCO_CREATE_NO_SMALL_LAUNCH) && !h->split16) {
-    if (small_launch_fn sf = find_small_launcher(fn)) {
+  if (h->want_small) {
+    if (small_launch_fn sf = small_fn) {
       h->small_max_nt[0] = (int)sf(nullptr, 0, 0, nullptr);
       h->small_max_nt[1] = (int)sf(nullptr, 1, 0, nullptr);
     if (h->small_max_nt[0] > 0 || h->small_max_nt[1] > 0) {
@@ -1116,7 +1140,7 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
       h->ssd = small_dims(d.D, d.De, d.Dh, h->fold2);
       const SmallDims& S = h->ssd;
       std::vector<float> t;
-      t.reserve((size_t)((d.M - 1) * S.step(d.L) + 64) * 4 * 256);
+      t.reserve((size_t)((d.M - 1) * S.step(d.L) + 64) * kSmallWaves * 256);
       for (int m = 1; m < d.M; ++m) {
         const size_t start = t.size();
         pack_small_section(t, w->cat_w[m] + d.De, d.De, d.D, d.De + d.D);
@@ -1126,14 +1150,14 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
           pack_small_section(t, w->down[(size_t)m * d.L + l], d.De, d.Dh, d.Dh);
         }
         if (S.PROJ) pack_small_section(t, w->out_proj[m], d.D, d.De, d.De);
-        if ((long)((t.size() - start) / 1024) != S.step(d.L)) return bail(fail(QINCO_ERR_INVALID, "internal: small-form stream size mismatch"));
+        if ((long)((t.size() - start) / (256 * kSmallWaves)) != S.step(d.L)) return bail(fail(QINCO_ERR_INVALID, "internal: small-form stream size mismatch"));
       }
-      t.resize(t.size() + (size_t)64 * 4 * 256, 0.f);   // the rings prefetch up to PW <= 64 fragments per wave past the end
+      t.resize(t.size() + (size_t)64 * kSmallWaves * 256, 0.f);   // the rings prefetch up to PW <= 64 fragments per wave past the end
       float* dt = nullptr;
       if ((rc = upload(h, &dt, t.data(), t.size()))) return bail(rc);
       h->small_stream = reinterpret_cast<f32x4*>(dt);
       std::vector<SmallStep> ss(d.M);
-      for (int m = 1; m < d.M; ++m) ss[m] = SmallStep{h->ttab[m], h->ptab[m], h->codebook[m]};
+      for (int m = 1; m < d.M; ++m) ss[m] = SmallStep{h->ttab_s[m], h->ptab_s[m], h->cb_s[m]};
       if ((rc = dev_alloc(h, &h->small_steps, (size_t)d.M))) return bail(rc);
       if (hipMemcpy(h->small_steps, ss.data(), ss.size() * sizeof(SmallStep), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(QINCO_ERR_HIP, "hipMemcpy(small_steps) failed"));
@@ -1318,7 +1342,7 @@ static int small_nt(const qinco_handle_s* h, long R, bool dec) {
 // position of step m's fragments in the small-form stream (f32x4 units); body = past the in-kernel head sections
 static const f32x4* small_stream_at(const qinco_handle_s* h, int m, bool body) {
   const long frags = (long)(m - 1) * h->ssd.step(h->d.L) + (body ? h->ssd.head() : 0);
-  return h->small_stream + frags * 4 * 64;
+  return h->small_stream + frags * kSmallWaves * 64;
 }
 
 static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool decode = false, const PreselJob* pj = nullptr) {

@@ -22,13 +22,22 @@ CPU set of its GPU's NUMA node (qinco_amd/affinity.py).  Rank 0 prints ONE JSON 
 
 metric/unit: encode vectors/s (BASELINE.json "metric"); workload C2 = qinco2-L 8x8, D=128, A=16, B=8
 (BASELINE.json configs[1]) with seeded synthetic weights (no trained checkpoints offline).
-roofline: the fused codeword-MLP kernel (99.9 % of the FLOPs), fp32 MFMA bound.  `achieved` = ALGORITHMIC FLOPs per
-launch (rows x R_mlp) / mean launch duration measured with HIP events on the launch stream; `frac` =
-achieved / peak.  The kernel folds the row-independent head of the MLP out, so the matrix pipe executes
-fewer FLOPs than the algorithm counts: `frac_executed` = executed FLOPs / duration / peak is the pipe-utilisation figure
-(it cannot exceed 1; the algorithmic one can on short models).
+roofline: the fused codeword-MLP kernel (99.9 % of the FLOPs), fp32 MFMA bound.  The kernels take the row-independent head of
+the MLP out of the per-row work, so the matrix pipe EXECUTES fewer FLOPs than the reference's algorithm counts.
+  `frac`             = executed FLOPs per launch / mean launch duration / peak -- a pipe utilisation, <= 1 by construction; the
+                       library counts the executed FLOPs per launch from the kernel form that ran (qinco_profile_read2), the
+                       duration is HIP events on the launch stream; profiles/ holds the SQ_INSTS_VALU_MFMA_MOPS_F32 passes that
+                       check the count;
+  `achieved`         = `frac` x peak (TFLOP/s through the pipe);
+  `frac_algorithmic` = ALGORITHMIC FLOPs (rows x R_mlp) / duration / peak: the figure comparable with the
+                       reference's own FLOP count -- it exceeds `frac`, and 1 on short models.
 Also in the line (N = 1, measured after the timed region):
-  `decode`, `mse`, `beam1`, `batch_1024`, `split_f16` -- as in round 2;
+  `decode` -- every timed code row in one call; `decode_batch_1024`, `decode_batch_12288` -- the call sizes the reference
+          decodes at (compute_MSE: cfg.batch = 1024 rows per call, qinco_tasks.py:112-125; the search re-rank:
+          cfg.search.batch_size = 12 288, search_tasks.py:475-486), through the small-launch form of the fused MLP;
+  `parity` -- rows of the committed reference fixtures (tests/golden: inputs + the imported reference's own codes) that this
+          build reproduces, C1 .. C4, run here on the GPU;
+  `mse`, `beam1`, `batch_1024`, `split_f16` -- as in round 2;
   `c1` -- BASELINE configs[0] / the north_star's literal target (qinco1 8x8, greedy): vectors/s, roofline, the number of
           code rows equal to the oracle's on a 256-vector sample, and the oracle's own rate on that sample (CPU baseline);
   `c3`, `c4` -- BASELINE configs[2] (M = 16) and configs[3] (D = 768) at their bench batch, with roofline;
@@ -71,7 +80,7 @@ def pmc_traffic_per_row():
     """L2<->fabric bytes per MLP row from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
     WRITE_SIZE).  Counters cannot be read from inside this process, so the figure of the separate PMC run of this
     same command is scaled to this run's rows per launch."""
-    for name in ("r03_c2_traffic.json", "r02_c2_traffic.json", "r01_c2_traffic.json"):
+    for name in ("r04_c2_traffic.json", "r03_c2_traffic.json", "r02_c2_traffic.json", "r01_c2_traffic.json"):
         try:
             with open(ROOT / "profiles" / name) as f:
                 return float(json.load(f)["bytes_per_row"]), name
@@ -160,39 +169,43 @@ def synth_batch_device(torch, cfg, mean_t, std, n, seed, dev):
     return z * std + mean_t
 
 
-def mlp_roofline(pr):
-    launches = max(pr["mlp_launches"], 1)
-    avg_ms = pr["mlp_ms"] / launches
-    fpl = pr["mlp_flops"] / launches
-    ach = fpl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    return launches, avg_ms, fpl, ach
+def executed_flops(cfg, rows, groups, fold=True, fold2=True):
+    """The library's own count (csrc/qinco_hip.hip mlp_flops_executed, reported by qinco_profile_read2), restated for the tests:
+    FLOPs the matrix pipe executes for `rows` MLP rows in `groups` (vector, beam) groups.  Un-folded: the algorithmic count.  FOLD:
+    the concat Linear and in_proj leave the per-row work (a table per codeword + U = W_x xhat once per group); FOLD2: the first
+    up-projection too (Q = W_up[0] U per group).  The 16-row tile form (De > 384) has FOLD only."""
+    L = max(cfg.L, 1)
+    if not fold:
+        return rows * (2.0 * (cfg.De + cfg.D) * cfg.De + 4.0 * L * cfg.De * cfg.dh + (4.0 * cfg.D * cfg.De if cfg.De != cfg.D else 0.0))
+    per_row = 4.0 * L * cfg.De * cfg.dh + (2.0 * cfg.De * cfg.D if cfg.De != cfg.D else 0.0)
+    per_group = 2.0 * cfg.D * cfg.De
+    if fold2:
+        per_row -= 2.0 * cfg.De * cfg.dh
+        per_group += 2.0 * cfg.De * cfg.dh
+    return rows * per_row + groups * per_group
 
 
-def executed_share(cfg, Ae):
-    """FOLD / FOLD2 (mlp_kernel.hpp): the row-independent head of the MLP is not recomputed per row, so the MFMA executes
-    fewer FLOPs than the reference's algorithm counts.  Share of the algorithmic FLOPs the matrix pipe really executes."""
-    head = (2.0 * cfg.D * cfg.De if cfg.De != cfg.D else 0.0) + 2.0 * (cfg.De + cfg.D) * cfg.De   # FOLD
-    head += 2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0                                            # FOLD2
-    per_group = 2.0 * cfg.D * cfg.De + (2.0 * cfg.De * cfg.dh if cfg.L > 0 else 0.0)               # xproj
-    return 1.0 - (head - per_group / Ae) / cfg.mlp_flops_per_row()
-
-
-def roofline_dict(cfg, prof, dt=None, folded=True, kernel="qinco::mlp_kernel (+ its xproj pre-GEMM)"):
-    launches, avg_ms, fpl, ach = mlp_roofline(prof)
-    ex = executed_share(cfg, cfg.A or cfg.K) if folded else 1.0
-    d = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "frac_executed": ach * ex / PEAK_FP32_MFMA_TFLOPS,
-         "mfma_flops_executed_frac": ex, "mfma_pipe_tflops": ach * ex, "avg_launch_ms": avg_ms,
-         "launches": prof["mlp_launches"], "flops_per_launch": fpl}
+def roofline_dict(prof, dt=None, kernel="qinco::mlp_kernel (+ its xproj pre-GEMM)"):
+    """prof = QincoEngine.profile_read(): event time, launches, algorithmic and executed FLOPs of the fused-MLP launches."""
+    launches = max(prof["mlp_launches"], 1)
+    avg_ms = prof["mlp_ms"] / launches
+    sec = prof["mlp_ms"] * 1e-3
+    alg = prof["mlp_flops"] / sec / 1e12 if sec > 0 else 0.0
+    exe = prof["mlp_flops_executed"] / sec / 1e12 if sec > 0 else 0.0
+    d = {"bound": "mfma", "kernel": kernel, "achieved": exe, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+         "frac": exe / PEAK_FP32_MFMA_TFLOPS, "frac_algorithmic": alg / PEAK_FP32_MFMA_TFLOPS, "algorithmic_tflops": alg,
+         "executed_over_algorithmic_flops": (prof["mlp_flops_executed"] / prof["mlp_flops"]) if prof["mlp_flops"] else None,
+         "avg_launch_ms": avg_ms, "launches": prof["mlp_launches"], "flops_per_launch": prof["mlp_flops"] / launches,
+         "executed_flops_per_launch": prof["mlp_flops_executed"] / launches}
     if dt:
-        d["mlp_share_of_step_time"] = prof["mlp_ms"] * 1e-3 / dt
+        d["mlp_share_of_step_time"] = sec / dt
     return d
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # extra legs (N = 1, after the timed region)
 # ------------------------------------------------------------------------------------------------------------------
-def leg_workload(torch, dev, name, steps, batch, oracle_sample=0):
+def leg_workload(torch, dev, name, steps, batch, oracle_sample=0, decode_sizes=()):
     """One of BASELINE.json's other configurations at its bench batch: K distinct resident batches, timed like the headline,
     with the fused-MLP roofline.  oracle_sample > 0 (C1): that many vectors are also encoded by the oracle on the host --
     the count of identical code rows (the north_star's "bit-exact greedy codes") and the oracle's rate on the sample."""
@@ -218,7 +231,12 @@ def leg_workload(torch, dev, name, steps, batch, oracle_sample=0):
     out = {"workload": WORKLOAD_NAMES[name], "value": steps * batch / dt, "unit": "vectors/s", "steps": steps,
            "vectors_per_step": batch, "ms_per_step": dt / steps * 1e3, "A": cfg.A, "B": cfg.B, "M": cfg.M, "D": cfg.D,
            "gflop_per_vector": eng.flops_per_vector("encode") / 1e9,
-           "roofline": roofline_dict(cfg, prof, dt, kernel="qinco::mlp_kernel (+ xproj)" if cfg.De <= 384 else "qinco::mlp16_kernel")}
+           "roofline": roofline_dict(prof, dt, kernel="qinco::mlp_kernel (+ xproj)" if cfg.De <= 384 else "qinco::mlp16_kernel")}
+    if decode_sizes:      # decode of these codes at the reference's call sizes (leg_decode_calls)
+        codes_all = torch.cat(codes)
+        for rows in decode_sizes:
+            out[f"decode_batch_{rows}"] = leg_decode_calls(torch, dev, eng, cfg, codes_all, rows)
+        del codes_all
     if cfg.ivf:
         st = eng.ivf_last_stats()
         out["ivf"] = {"ivf_K": cfg.ivf_K, "exact_candidates_per_vector": st["candidates"] / batch, "fell_back_to_fp32_table": st["fell_back"],
@@ -302,6 +320,71 @@ def leg_encode_db_bvecs(torch, dev, n_db, batch, workload="C2"):
             "file_bytes": n_db * (cfg.D + 4), "file_write_s": t_write, "part_file_bytes": part_bytes,
             "path": "np.memmap (strided uint8 rows) -> encode_database -> QINCoHIP.__call__ -> qinco_encode_host -> part file in the "
                     "reference's format (deflated int64 codes, search_tasks.py:125-131)"}
+
+
+def leg_decode_calls(torch, dev, eng, cfg, codes_all, rows, min_calls=8):
+    """Decode in calls of `rows` code rows each (distinct rows per call, resident in HBM), the way the reference's loops call
+    model(codes, step="decode").  Below ~one 128-row workgroup per CU a call runs on the small-launch form of the fused MLP
+    (csrc/mlp_small_kernel.hpp): every step of a row tile in ONE launch.  Its bound stays the fp32 matrix pipe down to one 16-row
+    tile per CU (4096 rows); below that the launch cannot fill the chip -- 1024 rows are 64 workgroups on 256 CUs, which all
+    stream the step's weights from L2 / Infinity Cache: weight_stream_gb_per_s says how fast."""
+    n_all = int(codes_all.shape[0])
+    calls = max(min_calls, min(64, n_all // rows))
+    chunks = [codes_all[(i * rows) % max(n_all - rows + 1, 1):][:rows] for i in range(calls)]
+    eng.decode(chunks[0], check=False)
+    torch.cuda.synchronize(dev)
+    eng.profile_enable(True)
+    eng.profile_read()
+    t0 = time.perf_counter()
+    for c in chunks:
+        eng.decode(c, check=False)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    eng.check_codes()
+    rf = roofline_dict(prof, dt, kernel="qinco::mlp_small_kernel (all steps of a row tile in one launch)" if rows < 24576
+                       else "qinco::mlp_kernel per step (+ xproj)")
+    tiles = (rows + 15) // 16
+    weights_mb = (cfg.M_total - 1) * (cfg.mlp_flops_per_row() / 2.0) * 4 / 1e6      # fp32 weights of every step's MLP
+    wgs = min(tiles, 256) if tiles <= 256 else None
+    out = {"value": calls * rows / dt, "unit": "vectors/s", "rows_per_call": rows, "calls": calls, "us_per_call": dt / calls * 1e6,
+           "us_per_vector": dt / (calls * rows) * 1e6, "roofline": rf}
+    if wgs is not None and rf["avg_launch_ms"] > 0:
+        out["bound_note"] = (f"{tiles} row tiles of 16 on 256 CUs: at most {tiles / 256:.2f} of the matrix pipes have rows to work on; every one "
+                             f"of the {wgs} workgroups streams all {weights_mb:.0f} MB of MLP weights through L2")
+        out["weight_stream_gb_per_s"] = wgs * weights_mb * 1e6 / (rf["avg_launch_ms"] * 1e-3) / 1e9
+        out["frac_of_occupied_pipes"] = rf["frac"] / min(1.0, tiles / 256)
+    return out
+
+
+def parity_counts(torch, dev):
+    """Rows of the committed reference fixtures this build reproduces, on this GPU: tests/golden/<case>.npz holds the inputs and the
+    codes / reconstructions the IMPORTED REFERENCE produced for them (tests/golden/make_golden.py ran /root/reference in the build
+    container; nothing of it is needed here).  Codes: rows equal / rows; decode: max |xhat - reference| / max |reference| of the
+    reference's own codes."""
+    sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    from cases import case_model
+    from qinco_amd import QincoEngine
+    out = {}
+    for key, name in (("C1", "C1_qinco1_8x8"), ("C2", "C2_qinco2L_8x8_b8"), ("C2_beam1", "C2_qinco2L_8x8_b1"),
+                      ("C3", "C3_qinco2L_16x8_b8"), ("C4", "C4_qinco2L_d768_b8")):
+        try:
+            g = np.load(ROOT / "tests" / "golden" / f"{name}.npz")
+            cfg, sd = case_model(name)
+            eng = QincoEngine(cfg, sd, max_batch=256)
+            want = g["codes_wrapper"] if "codes_wrapper" in g.files else g["codes_base"]
+            got = eng.encode(torch.from_numpy(g["x"]).to(dev), code_dtype=np.int64).cpu().numpy()
+            same = int((got == want).all(axis=1).sum())
+            dec = eng.decode(torch.from_numpy(want).to(dev)).cpu().numpy()
+            ref = g["decoded"]
+            out[key] = {"codes_equal_to_reference": f"{same}/{len(want)}",
+                        "decode_max_rel_err": float(np.abs(dec - ref).max() / np.abs(ref).max()), "fixture": f"tests/golden/{name}.npz"}
+            eng.close()
+        except Exception as e:                                # noqa: BLE001 -- the headline must not depend on a fixture
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -497,12 +580,14 @@ def main():
         total_vecs = db_size
         value = total_vecs / dt if dt > 0 else 0.0
         mlp_row = cfg.mlp_flops_per_row()
-        rf = roofline_dict(cfg, prof, dt, kernel=("qinco::mlp_kernel (+ its xproj pre-GEMM)" if not args.split_f16 else
-                                                  "qinco::mlp_split_kernel (+ xproj_split): fp16 pipe, so frac against the fp32-MFMA peak exceeds 1"))
+        rf = roofline_dict(prof, dt, kernel=("qinco::mlp_kernel (+ its xproj pre-GEMM)" if not args.split_f16 else
+                                             "qinco::mlp_split_kernel (+ xproj_split): runs on the fp16 pipe, quoted against the fp32-MFMA peak"))
         bpr, bpr_src = pmc_traffic_per_row() if args.workload == "C2" else (None, None)
         rows_per_launch = rf["flops_per_launch"] / mlp_row
         rf["traffic"] = bpr * rows_per_launch if bpr else None
-        rf["traffic_unit"] = f"bytes per launch (L2<->fabric, PMC pass in profiles/{bpr_src})" if bpr else None
+        rf["traffic_unit"] = (f"bytes per launch, L2<->fabric: NOT measured in this process (counters cannot be read from inside it) -- "
+                              f"bytes per MLP row of the separate rocprofv3 --pmc pass of this command (profiles/{bpr_src}) x this "
+                              f"run's rows per launch") if bpr else None
         out = {
             "metric": ("encode vectors/sec (BigANN-shaped d=128 8x8, beam=%d)" % cfg.B) if args.workload in ("C1", "C2") else
                       ("encode vectors/sec (d=%d %dx8, beam=%d)" % (cfg.D, cfg.M, cfg.B)),
@@ -535,10 +620,11 @@ def main():
         if world == 1 and not args.no_extras and K > 0 and not strong:
             extras(torch, dev, args, cfg, sd, eng, out, mine, batches, warm, value, sqerr_sum, QincoEngine)
         if world == 1 and not args.no_legs and not args.split_f16:
-            for key, fn in (("c1", lambda: leg_workload(torch, dev, "C1", 3, 16384, oracle_sample=256)),
+            out["parity"] = parity_counts(torch, dev)
+            for key, fn in (("c1", lambda: leg_workload(torch, dev, "C1", 3, 16384, oracle_sample=256, decode_sizes=(1024, 12288, 16384))),
                             ("c3", lambda: leg_workload(torch, dev, "C3", 2, 16384)),
                             ("c4", lambda: leg_workload(torch, dev, "C4", 2, 16384)),
-                            ("qinco2_S", lambda: leg_workload(torch, dev, "S", 6, 16384)),
+                            ("qinco2_S", lambda: leg_workload(torch, dev, "S", 6, 16384, decode_sizes=(1024, 12288, 16384))),
                             ("ivf_qinco2_S", lambda: leg_workload(torch, dev, "IVF_S", 6, 16384)),
                             ("encode_db_bvecs", lambda: leg_encode_db_bvecs(torch, dev, args.bvecs_vectors, 16384)),
                             ("encode_db_bvecs_qinco2S", lambda: leg_encode_db_bvecs(torch, dev, args.bvecs_vectors, 16384, "S"))):
@@ -578,14 +664,13 @@ def extras(torch, dev, args, cfg, sd, eng, out, mine, batches, warm, value, sqer
     prd = eng.profile_read()
     eng.profile_enable(False)
     eng.check_codes()
-    _, d_ms, _, d_ach = mlp_roofline(prd)
-    # decode runs the shape's un-folded instance when it has one (csrc/shapes.def), else the folded encode instance
-    d_exec = 1.0 if "decode_var=-1" not in eng.describe() and not args.split_f16 else executed_share(cfg, 1)
     out["decode"] = {"value": codes_all.shape[0] / dt_dec, "unit": "vectors/s", "vectors": int(codes_all.shape[0]),
                      "gflop_per_vector": eng.flops_per_vector("decode") / 1e9,
-                     "roofline": {"bound": "mfma", "achieved": d_ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": d_ach / PEAK_FP32_MFMA_TFLOPS,
-                                  "frac_executed": d_ach * d_exec / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": d_ms}}
+                     "roofline": roofline_dict(prd, dt_dec, kernel="qinco::mlp_kernel per step (+ xproj)")}
+    # ---- decode at the reference's own call sizes: compute_MSE decodes cfg.batch = 1024 rows per call (qinco_tasks.py:112-125,
+    # qinco_cfg.yaml:38), the search re-rank cfg.search.batch_size = 12 288 (search_tasks.py:475-486, qinco_cfg.yaml:137) ----
+    for key, rows in (("decode_batch_1024", 1024), ("decode_batch_12288", 12288), ("decode_batch_16384", 16384)):
+        out[key] = leg_decode_calls(torch, dev, eng, cfg, codes_all, rows)
     xs = torch.cat(batches)
     out["mse"] = {"value": sqerr_sum(xs, dec) / xs.shape[0], "vectors": int(xs.shape[0]),
                   "definition": "sum_i |x_i - decode(encode(x_i))|^2 / N (mse_scale 1; metrics.py:51-58)"}
@@ -630,7 +715,9 @@ def extras(torch, dev, args, cfg, sd, eng, out, mine, batches, warm, value, sqer
         dt2 = time.perf_counter() - t3
         pr2 = eng2.profile_read()
         eng2.profile_enable(False)
-        _, s_ms, s_fpl, s_ach = mlp_roofline(pr2)
+        s_launches = max(pr2["mlp_launches"], 1)
+        s_ms, s_fpl = pr2["mlp_ms"] / s_launches, pr2["mlp_flops"] / s_launches
+        s_ach = s_fpl / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
         differ = int((codes2 != codes_all).any(dim=1).sum().item())
         dec2 = eng2.decode(codes2, check=False)
         xs = torch.cat(batches)

@@ -171,6 +171,11 @@ QINCO_API int qinco_decode_host(qinco_handle h, const void* codes, int code_dtyp
  * its own stream.  qinco_profile_read synchronises, returns the totals since the last read and resets them. */
 QINCO_API int qinco_profile_enable(qinco_handle h, int enable);
 QINCO_API int qinco_profile_read(qinco_handle h, double* mlp_ms, int64_t* mlp_launches, double* mlp_flops);
+/* ... and the FLOPs the matrix pipe EXECUTED for those launches.  mlp_flops is the reference algorithm's count (rows x R_mlp,
+ * SURVEY.md 8d); the kernels take the row-independent head of the MLP out of the per-row work (a table per codeword, one small GEMM
+ * per (vector, beam) group: csrc/mlp_kernel.hpp FOLD / FOLD2), so they execute fewer: executed / time / peak is a pipe utilisation
+ * (<= 1 by construction), algorithmic / time / peak is not.  Counted per launch from the kernel form that ran. */
+QINCO_API int qinco_profile_read2(qinco_handle h, double* mlp_ms, int64_t* mlp_launches, double* mlp_flops, double* mlp_flops_executed);
 
 /* Algorithmic FLOPs of one vector's encode / decode at the handle's current A, B. */
 QINCO_API double qinco_flops_per_vector_encode(qinco_handle h);

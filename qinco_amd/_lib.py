@@ -17,7 +17,7 @@ CREATE_SPLIT_NO_CALIBRATION, CREATE_NO_PRESEL_FUSION, CREATE_NO_SMALL_LAUNCH = 3
 # every symbol include/qinco_hip.h declares (tests check the library exports all of them)
 API_SYMBOLS = [
     "qinco_create", "qinco_create_ex", "qinco_create_opt", "qinco_describe", "qinco_padded_shape", "qinco_load_instance", "qinco_split_stats", "qinco_gather_codes", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
-    "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_flops_per_vector_encode",
+    "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_profile_read2", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
     "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
     "qinco_ivf_last_stats", "qinco_check", "qinco_selftest", "qinco_knn_create", "qinco_knn_destroy", "qinco_knn_search", "qinco_knn_search_host", "qinco_sqerr_sum",
@@ -123,6 +123,8 @@ def load() -> C.CDLL:
     lib.qinco_check.restype = C.c_int
     lib.qinco_profile_enable.argtypes = [vp, i32]
     lib.qinco_profile_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl)]
+    lib.qinco_profile_read2.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
+    lib.qinco_profile_read2.restype = C.c_int
     lib.qinco_flops_per_vector_encode.argtypes = [vp]
     lib.qinco_flops_per_vector_encode.restype = dbl
     lib.qinco_flops_per_vector_decode.argtypes = [vp]

@@ -204,6 +204,12 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
       static_for<NOW>([&]<int j>() QINCO_LAMBDA {
         f32x4 wv = wf[j];
         pin4_v(wv);   // this fragment's LDS read -- and, LDS returning a wave's reads in order, every earlier one -- has completed
+        // Waves w and w + 4 share a SIMD; left alone the older one wins every arbitration, runs ahead and then idles at the barrier
+        // while its partner finishes alone at a single wave's issue rate.  Taking turns at the higher priority, two fragments at a
+        // time and in opposite phases, keeps both in step: -4 % (qinco2-S) ... -7 % (qinco2-L) on a decode (scripts/gpu_small_prio_sweep.sh,
+        // profiles/r04_small_prio.log; one turn per fragment, four per turn, or a fixed priority for one of them: all slower).
+        if ((((ib * NOW + j) >> 1) & 1) ^ (wave_u >> 2)) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
         if constexpr (!LAST) {
           constexpr int r = (ib + 1) * NOW + j;   // index of this read within the GEMM
           wf[j] = ring_read.template operator()<hosted_extra(r, NOW, G, GPF, WIN)>();

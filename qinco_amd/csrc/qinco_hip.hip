@@ -212,7 +212,8 @@ struct qinco_handle_s {
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
-  double prof_flops = 0.0;
+  double prof_flops = 0.0;        // algorithmic (rows x R_mlp)
+  double prof_flops_exec = 0.0;   // what the matrix pipe executes for them (the folded head is tables + one GEMM per group)
 
   std::vector<void*> owned;  // every device allocation, for destroy
 #ifdef QINCO_TIMELINE
@@ -240,6 +241,24 @@ static double mlp_flops_per_row(const qinco_handle_s* h) {
   double f = 2.0 * (d.De + d.D) * d.De + 4.0 * d.L * (double)d.De * d.Dh;
   if (d.De != d.D) f += 4.0 * d.D * d.De;
   return f;
+}
+
+// FLOPs the matrix pipe EXECUTES for a fused-MLP launch of R rows in G groups (model dimensions, not the padded ones):
+//   un-folded instance (decode twin):      the algorithmic count, R x R_mlp;
+//   FOLD:   R x (4 L De Dh + [De != D] 2 De D)  +  G x 2 D De                       (U = W_x xhat once per group);
+//   FOLD2:  R x ((4 L - 2) De Dh + [De != D] 2 De D)  +  G x (2 D De + 2 De Dh)     (Q = W_up[0] U too);
+//   decode in one launch of the small form: every row is its own group, U and Q are computed per row.
+static double mlp_flops_executed(const qinco_handle_s* h, double R, double G, bool folded, bool fold2) {
+  const qinco_desc& d = h->user;
+  const double L = h->d.L;   // (a model without FFN blocks runs one all-zero block)
+  if (!folded) return R * (2.0 * (d.De + d.D) * d.De + 4.0 * L * d.De * d.Dh + (d.De != d.D ? 4.0 * d.D * d.De : 0.0));
+  double per_row = 4.0 * L * d.De * d.Dh + (d.De != d.D ? 2.0 * d.De * d.D : 0.0);
+  double per_group = 2.0 * d.D * d.De;
+  if (fold2) {
+    per_row -= 2.0 * d.De * d.Dh;
+    per_group += 2.0 * d.De * d.Dh;
+  }
+  return R * per_row + G * per_group;
 }
 
 template <class T>
@@ -1427,6 +1446,7 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
   if (h->prof) {
     HIP_TRY(hipEventRecord(e1, st));
     h->prof_flops += (double)a.R * mlp_flops_per_row(h);
+    h->prof_flops_exec += mlp_flops_executed(h, (double)a.R, (double)(a.R / a.A), h->fold && !unfolded, h->fold2 && !unfolded);
   }
   return 0;
 }
@@ -1710,6 +1730,7 @@ static int decode_chunk(qinco_handle_s* h, const void* codes, int code_dtype, in
     if (h->prof) {
       HIP_TRY(hipEventRecord(e1, st));
       h->prof_flops += (double)n * (M - 1) * mlp_flops_per_row(h);
+      h->prof_flops_exec += mlp_flops_executed(h, (double)n * (M - 1), (double)n * (M - 1), true, h->fold2);
     }
     return 0;
   }
@@ -1863,7 +1884,7 @@ extern "C" int qinco_profile_enable(qinco_handle h, int enable) {
   return QINCO_OK;
 }
 
-extern "C" int qinco_profile_read(qinco_handle h, double* mlp_ms, int64_t* mlp_launches, double* mlp_flops) {
+extern "C" int qinco_profile_read2(qinco_handle h, double* mlp_ms, int64_t* mlp_launches, double* mlp_flops, double* mlp_flops_executed_out) {
   if (!h) return fail(QINCO_ERR_INVALID, "qinco_profile_read: null handle");
   HIP_TRY(hipDeviceSynchronize());
   double ms = 0.0;
@@ -1875,9 +1896,15 @@ extern "C" int qinco_profile_read(qinco_handle h, double* mlp_ms, int64_t* mlp_l
   if (mlp_ms) *mlp_ms = ms;
   if (mlp_launches) *mlp_launches = (int64_t)h->ev_used;
   if (mlp_flops) *mlp_flops = h->prof_flops;
+  if (mlp_flops_executed_out) *mlp_flops_executed_out = h->prof_flops_exec;
   h->ev_used = 0;
   h->prof_flops = 0.0;
+  h->prof_flops_exec = 0.0;
   return QINCO_OK;
+}
+
+extern "C" int qinco_profile_read(qinco_handle h, double* mlp_ms, int64_t* mlp_launches, double* mlp_flops) {
+  return qinco_profile_read2(h, mlp_ms, mlp_launches, mlp_flops, nullptr);
 }
 
 extern "C" double qinco_flops_per_vector_encode(qinco_handle h) {

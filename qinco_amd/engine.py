@@ -235,9 +235,11 @@ class QincoEngine:
         _lib.check(self.lib.qinco_profile_enable(self._h, int(on)))
 
     def profile_read(self):
-        ms, cnt, fl = C.c_double(), C.c_int64(), C.c_double()
-        _lib.check(self.lib.qinco_profile_read(self._h, C.byref(ms), C.byref(cnt), C.byref(fl)))
-        return {"mlp_ms": ms.value, "mlp_launches": cnt.value, "mlp_flops": fl.value}
+        """Totals of the fused-MLP launches since the last read: event time, launches, algorithmic FLOPs (rows x R_mlp) and the
+        FLOPs the matrix pipe executed for them (qinco_profile_read2)."""
+        ms, cnt, fl, fx = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(self.lib.qinco_profile_read2(self._h, C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(fx)))
+        return {"mlp_ms": ms.value, "mlp_launches": cnt.value, "mlp_flops": fl.value, "mlp_flops_executed": fx.value}
 
     def ivf_last_stats(self) -> dict:
         """IVF models: exact-pass candidate pairs and fall-back flag of the last IVF assignment (qinco_ivf_last_stats)."""

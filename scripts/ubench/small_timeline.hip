@@ -23,7 +23,50 @@
 
 using namespace qinco;
 
+// Calibration: what does __builtin_readcyclecounter() count, and at what clock does the matrix pipe run?  One wave per SIMD issues N
+// independent v_mfma_f32_16x16x4_f32 (32 pipe cycles each) between two stamps; HIP events give the wall time of the same launch.
+__global__ void __launch_bounds__(256, 1) calib_kernel(int n, unsigned long long* ticks, float* sink) {
+  f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  const float av = 1.0f + threadIdx.x * 1e-9f, bv = 0.5f;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < n; i += 16) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k & 3] = QINCO_MFMA16(av, bv, acc[k & 3]);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+  if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 123.456f) sink[0] = 1.f;
+}
+
+static void calibrate() {
+  const int n = 1 << 18, grid = 256;
+  unsigned long long* dt;
+  float* ds;
+  CHECK(hipMalloc(&dt, grid * 4 * 8));
+  CHECK(hipMalloc(&ds, 4));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 3; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(calib_kernel, dim3(grid), dim3(256), 0, 0, n, dt, ds);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> t(grid * 4);
+    CHECK(hipMemcpy(t.data(), dt, t.size() * 8, hipMemcpyDeviceToHost));
+    std::sort(t.begin(), t.end());
+    const double med = (double)t[t.size() / 2];
+    printf("calibration %d: %d MFMAs per wave (%.0f pipe cycles) in %.1f us: %.0f ticks (%.3f ticks per pipe cycle), %.3f ticks/ns, "
+           "pipe clock if one MFMA per 32 cycles: %.3f GHz\n", rep, n, n * 32.0, ms * 1e3, med, med / (n * 32.0), med / (ms * 1e6),
+           n * 32.0 / (ms * 1e6));
+  }
+}
+
 int main(int argc, char** argv) {
+  calibrate();
   const long R = argc > 1 ? atol(argv[1]) : 12288;
   const int steps = argc > 2 ? atoi(argv[2]) : 7;
   const int L = argc > 3 ? atoi(argv[3]) : 2;

@@ -105,7 +105,10 @@ enum {
   QINCO_CREATE_TABLE_NO_COOP = 16,
   QINCO_CREATE_SPLIT_NO_CALIBRATION = 32,  /* skip the create-time comparison with the fp32 instance (below) */
   QINCO_CREATE_NO_PRESEL_FUSION = 64,      /* diagnostics: pre-selection table and xproj as two launches at every launch size */
-  QINCO_CREATE_NO_SMALL_LAUNCH = 128       /* diagnostics: the 128-rows-per-workgroup kernels at every launch size */
+  QINCO_CREATE_NO_SMALL_LAUNCH = 128,      /* diagnostics: the 128-rows-per-workgroup kernels at every launch size */
+  QINCO_CREATE_NO_EPILOGUE_SELECT = 256    /* diagnostics: candidates and distances always written back, beam_select_kernel always run
+                                              (default: identity-projection models whose F * A candidates per vector fit a workgroup
+                                              take the per-vector top-B in the fused-MLP kernel's epilogue, csrc/mlp_kernel.hpp SELEP) */
 };
 
 /* The split form checks itself.  (1) At create, unless QINCO_CREATE_SPLIT_NO_CALIBRATION: the model is also built as an fp32

@@ -208,27 +208,7 @@ beam_select_kernel(const float* __restrict__ dist, const float* __restrict__ can
   const float* dsrc = dist + n * C;
   for (int k = lane; k < C; k += 64) dv[k] = dsrc[k];
   __builtin_amdgcn_wave_barrier();
-  int rank, index;
-  if (T > 1 && wave_select_smallest(dv, C, T, surv, lane, rank, index)) {
-    if (rank >= 0) sel[rank] = index;
-  } else {   // T == 1 (one arg-min round is already minimal), or massive ties: T rounds of arg-min
-    for (int t = 0; t < T; ++t) {
-      float bv = __builtin_inff();
-      int bi = 0x7fffffff;
-      for (int k = lane; k < C; k += 64) {  // k ascends: strict < keeps the lowest index
-        const float v = dv[k];
-        const bool take = v < bv;
-        bv = take ? v : bv;
-        bi = take ? k : bi;
-      }
-      wave_argmin(bv, bi);
-      if (bi == 0x7fffffff) bi = 0;           // only NaN / +inf left: degenerate, keep in range
-      if ((bi & 63) == lane) dv[bi] = __builtin_inff();
-      if (lane == 0) sel[t] = bi;
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
+  wave_top_t(dv, C, T, surv, sel, lane);
   // parents, codes, history re-threading and the xhat gather of all T survivors, spread over the 64 lanes
   for (int e = lane; e < T * (m + 1); e += 64) {
     const int t = e / (m + 1), j = e - t * (m + 1);

@@ -14,7 +14,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // Bumped by hand whenever the MEANING of an argument block or of a launcher changes without changing its size (instance_abi).
-constexpr int kInstanceAbiVersion = 2;
+constexpr int kInstanceAbiVersion = 3;
 
 // Fragment (1 KiB = 64 lanes x float4) counts of each section of the packed per-step weight stream.
 // Every section is padded to a multiple of the ring depth P so ring slots are compile-time constants.
@@ -68,6 +68,13 @@ struct MlpArgs {
   int* err;               // split-fp16 form: sticky flag, set to 2 when a candidate distance is not finite (fp16 overflow)
   const float* smul;      // split-fp16 form (mlp_split_kernel.hpp): [2^c, 2^-c, then per FFN block l: m_up[l], m_down[l]]
   unsigned long long* stats;  // split-fp16 form: [elements sampled, elements whose fp16 lo part is subnormal] (every 64th workgroup)
+  // SELEP instances (mlp_kernel.hpp): sel_T > 0 = the per-vector top-T of the step is taken in the kernel's epilogue (beam_select_kernel's
+  // job: qinco_inference.py:200-222) -- needs the vector's F * A candidates inside one workgroup (128 % (F A) == 0); nothing is
+  // written to cand_out / dist_out then, only the T winners: their rows to sel_xhat_out, their code histories to sel_hist_out
+  int sel_T, sel_m, sel_M;    // beams kept, step index, codes per history row
+  const int* sel_hist_in;     // (N, F, M)
+  int* sel_hist_out;          // (N, T, M)
+  float* sel_xhat_out;        // (N, T, D)
 #ifdef QINCO_TIMELINE     // experiment builds only (scripts/exp_timeline.py): per-wave cycle stamps of the kernel's phases
   unsigned long long* timeline;   // (tiles, 8)
 #endif

@@ -52,7 +52,7 @@ hipError_t QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::Mlp
 #ifdef QINCO_INSTANCE_MODULE
 #include "ivf_kernel.hpp"
 #include "table_kernel.hpp"
-#if (QVAR & 16) && !(QVAR & 512)   // a folded fp32 instance: the module also brings the small-launch form of its shape
+#if (QVAR & 16) && !(QVAR & (512 | 128))   // a folded fp32 32-row instance: the module also brings the small-launch form of its shape
 #define QF2 ((QVAR & 32) ? 1 : 0)
 #define QINCO_MODULE_HAS_SMALL 1
 #define QINCO_SMALL_FN_NAME qinco_module_small_launch

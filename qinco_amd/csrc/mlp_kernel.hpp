@@ -37,10 +37,17 @@
 //             W_up[0] z = P[cid] + Q[group] with P = W_up[0] T (table) and Q = W_up[0] U (same xproj launch), so the
 //             kernel starts with y = relu(P[cid] + Q[group]) and the first down-projection: -2.9 % more at C2, -20 %
 //             for the two-block qinco2-S.
+// 2048 SELEP  (identity projections, shared ring) the step's per-vector top-T in the epilogue, when MlpArgs::sel_T > 0 and a vector's
+//             F * A candidates sit inside one workgroup (128 % (F A) == 0): the candidates stay in z's registers, their
+//             distances meet in LDS, one wave per vector runs beam_select_kernel's selection (select.hpp wave_top_t), and only the T
+//             winners are stored -- rows straight into the next step's xhat, codes into its history.  No candidate / distance
+//             write-back (512 + 4 B per row of which the selection used 1/16), no beam_select launch.  Same distances, same
+//             selection: bit-identical codes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <utility>
 #include "mlp_args.hpp"
+#include "select.hpp"
 
 namespace qinco {
 
@@ -112,7 +119,9 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   constexpr bool PINNED = (VAR & 8) != 0;
   constexpr bool SHR = (VAR & 64) != 0;
   constexpr bool G8 = (VAR & 1024) != 0;   // shared ring with a barrier / refill every 8 fragments instead of every 4 (A/B variant)
-  static_assert((VAR & ~(4 | 8 | 16 | 32 | 64 | 256 | 1024)) == 0, "unknown VAR bits");
+  constexpr bool SELEP = (VAR & 2048) != 0;
+  static_assert((VAR & ~(4 | 8 | 16 | 32 | 64 | 256 | 1024 | 2048)) == 0, "unknown VAR bits");
+  static_assert(!SELEP || (SHR && D == DE), "SELEP: every wave reaches the epilogue's barriers, candidates live in z's registers");
   static_assert(!G8 || (SHR && P % 24 == 0 && P / 4 >= 7), "G8 is a form of the shared ring");
   static_assert(!OCC2 || (VAR & 8), "OCC2 is a form of the pinned plan");
   static_assert(!SHR || (LDSR && P % 12 == 0 && P / 4 >= 5), "shared ring: P multiple of 12 (3 register sets, 4 issuers)");
@@ -459,6 +468,76 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   }
 
   stamp(3);   // FFN blocks done
+  if constexpr (SELEP) {
+    if (a.sel_T > 0) {   // (a kernel argument: uniform over the launch)
+      // ---- E': candidates in place (z <- (z + coeff*c) + xhat), distances, per-vector top-T, winners only ----------------------
+      const long nv = g / a.F;
+      const float* xptr = a.x + nv * D + half * 4;
+      float s2 = 0.f, sx = 0.f, xn = 0.f;
+      static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
+        f32x16 o = z[ob];
+        if (a.add_c) o = o + load_block(cptr + ob * 32);
+        o = o + load_block(xhptr + ob * 32);
+        const f32x16 xb = load_block(xptr + ob * 32);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {   // (the order of the generic epilogue below: the same distances to the bit)
+          s2 = fmaf(o[i], o[i], s2);
+          sx = fmaf(o[i], xb[i], sx);
+          xn = fmaf(xb[i], xb[i], xn);
+        }
+        z[ob] = o;
+      });
+      s2 += __shfl_xor(s2, 32);
+      sx += __shfl_xor(sx, 32);
+      xn += __shfl_xor(xn, 32);
+      const float dist = (xn + s2) - 2.f * sx;
+      __shared__ float sel_dv[128];
+      __shared__ int sel_idx[128];
+      __shared__ int sel_rank[128];
+      __shared__ unsigned long long sel_surv[4 * SEL_SURV];
+      auto lds_barrier = [&]() QINCO_LAMBDA {   // (raw: __syncthreads would also wait for the ring's tail DMAs)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      };
+      const int rl = wave * 32 + j;   // row within the workgroup
+      if (half == 0) {
+        sel_dv[rl] = dist;
+        sel_rank[rl] = -1;
+      }
+      lds_barrier();
+      const int C = a.A * a.F, T = a.sel_T;
+      const long n0 = ((long)blockIdx.x * 128) / C, nvec = a.R / C;
+      for (int v = wave_u; v < 128 / C; v += 4) {   // one wave per vector of the workgroup
+        if (n0 + v < nvec) {
+          wave_top_t(sel_dv + v * C, C, T, sel_surv + wave_u * SEL_SURV, sel_idx + v * C, lane);
+          for (int t = lane; t < T; t += 64) sel_rank[v * C + sel_idx[v * C + t]] = t;
+        }
+      }
+      lds_barrier();
+      const int rk = sel_rank[rl];
+      if (valid && rk >= 0) {
+        const long orow = nv * T + rk;
+        float* outp = a.sel_xhat_out + orow * D + half * 4;
+        static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 t = {z[ob][4 * q], z[ob][4 * q + 1], z[ob][4 * q + 2], z[ob][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(outp + ob * 32 + 8 * q) = t;
+          }
+        });
+        if (half == 0) {   // the winner's code history: its parent beam's codes, then its own (qinco_inference.py:203-210)
+          const int* hin = a.sel_hist_in + g * a.sel_M;
+          int* hout = a.sel_hist_out + orow * a.sel_M;
+          for (int jj = 0; jj < a.sel_m; ++jj) hout[jj] = hin[jj];
+          hout[a.sel_m] = cid;
+        }
+      }
+      if constexpr (LDSR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
+  }
   // ---- E: out_proj + epilogue: cand = (out + coeff*c) + xhat ; dist = |x|^2 + |cand|^2 - 2 x.cand
   const long n = g / a.F;
   const float* xptr = a.x ? a.x + n * D + half * 4 : nullptr;

@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
     const f32x4 v = ring[rd_slot * 64 + lane];
     asm volatile("" ::: "memory");
     dma(wr_slot);
+    asm volatile("" ::: "memory");   // loads hosted behind this read stay behind its DMA (hosted_extra counts them as younger)
     rd_slot = rd_slot + 1 == PW ? 0 : rd_slot + 1;
     wr_slot = wr_slot + 1 == PW ? 0 : wr_slot + 1;
     return v;

@@ -59,7 +59,7 @@ static const SmallInstance g_small[] = {
 };
 // ... of an fp32 instance with the folded head (the small form starts from z = T[codeword] + U[group] like it)
 static small_launch_fn find_small_launcher(const MlpInstance* i) {
-  if (!i || !(i->var & 16) || (i->var & 512)) return nullptr;
+  if (!i || !(i->var & 16) || (i->var & (512 | 128))) return nullptr;   // (not the split form, not the 16-row tile form: other orders)
   if (i->small) return i->small;
   for (const SmallInstance& s : g_small)
     if (s.D == i->D && s.De == i->De && s.Dh == i->Dh && s.fold2 == ((i->var & 32) ? 1 : 0)) return s.fn;
@@ -151,6 +151,8 @@ struct qinco_handle_s {
   // through HBM.  When the shape has an un-folded instance, decode uses it with its own (complete) weight stream.
   const MlpInstance* dec_inst = nullptr;
   StreamDims dec_sd{};
+  // the encode instance with the per-vector top-T in its epilogue (VAR bit 2048, same weight stream), when the shape has one
+  const MlpInstance* sel_inst = nullptr;
   std::vector<f32x4*> dec_wstream;
   // small-launch form (mlp_small_kernel.hpp): its weight stream (every step, contiguous), per-step table pointers, largest NT
   small_launch_fn small = nullptr;
@@ -200,13 +202,8 @@ struct qinco_handle_s {
   int64_t dec_cap = 0;
   float* dxhat[2] = {nullptr, nullptr};
 
-  // host-path staging
-  void* stage_x = nullptr;
-  size_t stage_x_bytes = 0;
-  void* stage_codes = nullptr;
-  size_t stage_codes_bytes = 0;
-  float* stage_out = nullptr;
-  size_t stage_out_bytes = 0;
+  // host-path staging: a two-deep pipeline of pinned host buffers and device buffers (HostPipe below)
+  struct HostPipe* pipe = nullptr;
 
   // profiling
   bool prof = false;
@@ -275,6 +272,73 @@ static void dev_free(qinco_handle_s* h, void* p) {
   for (auto& q : h->owned)
     if (q == p) { q = nullptr; break; }
   (void)hipFree(p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-pointer entry points: a two-deep pipeline.  The reference's loop is H2D -> encode -> D2H per batch (search_tasks.py:107-116); done
+// one after the other the GPU idles during both copies (and pageable copies are staged by the runtime at a few GB/s).  Here pass
+// k + 1 is packed into a PINNED host buffer and copied in on its own stream, and the codes of pass k - 1 are copied out on a
+// third, while the kernels of pass k run: two buffers of each kind, three streams, events between them.  Three slots per side:
+//   in:  host hx[b] (pinned) -> device dx[b]      out A (codes / decode input):  device da[b] <-> host ha[b] (pinned)
+//   out B (xhat of encode / x of decode): device db_[b] -> host hb[b] (pinned)
+// ---------------------------------------------------------------------------------------------
+struct HostPipe {
+  hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
+  hipEvent_t in_ready[2] = {nullptr, nullptr}, comp_done[2] = {nullptr, nullptr}, out_ready[2] = {nullptr, nullptr};
+  void* hbuf[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // pinned host: [x | codes | floats][slot]
+  void* dbuf[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // device
+  size_t cap[3] = {0, 0, 0};
+};
+
+static void host_pipe_destroy(HostPipe* p) {
+  if (!p) return;
+  for (int k = 0; k < 3; ++k)
+    for (int b = 0; b < 2; ++b) {
+      if (p->hbuf[k][b]) (void)hipHostFree(p->hbuf[k][b]);
+      if (p->dbuf[k][b]) (void)hipFree(p->dbuf[k][b]);
+    }
+  for (int b = 0; b < 2; ++b) {
+    if (p->in_ready[b]) (void)hipEventDestroy(p->in_ready[b]);
+    if (p->comp_done[b]) (void)hipEventDestroy(p->comp_done[b]);
+    if (p->out_ready[b]) (void)hipEventDestroy(p->out_ready[b]);
+  }
+  if (p->s_in) (void)hipStreamDestroy(p->s_in);
+  if (p->s_comp) (void)hipStreamDestroy(p->s_comp);
+  if (p->s_out) (void)hipStreamDestroy(p->s_out);
+  delete p;
+}
+
+// streams, events and the three buffer kinds at (at least) the given sizes
+static int host_pipe_ensure(HostPipe** pp, const size_t (&need)[3]) {
+  if (!*pp) {
+    HostPipe* p = new HostPipe();
+    *pp = p;
+    HIP_TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p->s_comp, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      HIP_TRY(hipEventCreateWithFlags(&p->in_ready[b], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&p->comp_done[b], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&p->out_ready[b], hipEventDisableTiming));
+    }
+  }
+  HostPipe* p = *pp;
+  for (int k = 0; k < 3; ++k) {
+    if (need[k] <= p->cap[k]) continue;
+    HIP_TRY(hipDeviceSynchronize());
+    for (int b = 0; b < 2; ++b) {
+      if (p->hbuf[k][b]) (void)hipHostFree(p->hbuf[k][b]);
+      if (p->dbuf[k][b]) (void)hipFree(p->dbuf[k][b]);
+      p->hbuf[k][b] = p->dbuf[k][b] = nullptr;
+    }
+    p->cap[k] = 0;
+    for (int b = 0; b < 2; ++b) {
+      HIP_TRY(hipHostMalloc(&p->hbuf[k][b], need[k], hipHostMallocDefault));
+      HIP_TRY(hipMalloc(&p->dbuf[k][b], need[k]));
+    }
+    p->cap[k] = need[k];
+  }
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -832,7 +896,7 @@ struct CreateOpts {
 };
 static const int kCreateFlagMask = QINCO_CREATE_SPLIT_F16 | QINCO_CREATE_IVF_FP32 | QINCO_CREATE_TABLE_VALU | QINCO_CREATE_DECODE_FOLDED |
                                    QINCO_CREATE_TABLE_NO_COOP | QINCO_CREATE_SPLIT_NO_CALIBRATION | QINCO_CREATE_NO_PRESEL_FUSION |
-                                   QINCO_CREATE_NO_SMALL_LAUNCH;
+                                   QINCO_CREATE_NO_SMALL_LAUNCH | QINCO_CREATE_NO_EPILOGUE_SELECT;
 
 static void env_opts(CreateOpts& o) {
 #ifdef QINCO_EXPERIMENT
@@ -843,6 +907,7 @@ static void env_opts(CreateOpts& o) {
   if (getenv("QINCO_TABLE_NO_COOP")) o.flags |= QINCO_CREATE_TABLE_NO_COOP;
   if (getenv("QINCO_NO_PRESEL_FUSION")) o.flags |= QINCO_CREATE_NO_PRESEL_FUSION;
   if (getenv("QINCO_NO_SMALL_LAUNCH")) o.flags |= QINCO_CREATE_NO_SMALL_LAUNCH;
+  if (getenv("QINCO_NO_EPILOGUE_SELECT")) o.flags |= QINCO_CREATE_NO_EPILOGUE_SELECT;
   if (const char* e = getenv("QINCO_TABLE_COOP_MAX")) o.table_coop_max = atol(e);
   if (const char* e = getenv("QINCO_MLP_VARIANT")) sscanf(e, "%d,%d", &o.mlp_P, &o.mlp_var);
 #else
@@ -989,6 +1054,10 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
       h->dec_inst = di;
       h->dec_sd = stream_dims(d.D, d.De, d.Dh, di->P, false, false, 32);
     }
+  }
+  if (fn && !(create_flags & QINCO_CREATE_NO_EPILOGUE_SELECT) && !(fn->var & 2048) && d.De == d.D && want_var < 0) {
+    const MlpInstance* si = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var | 2048);
+    if (si && si->P == fn->P && si->var == (fn->var | 2048)) h->sel_inst = si;
   }
   int rc = 0;
   auto bail = [&](int code) {
@@ -1284,9 +1353,7 @@ extern "C" int qinco_destroy(qinco_handle h) {
   (void)hipDeviceSynchronize();
   for (void* p : h->owned)
     if (p) (void)hipFree(p);
-  if (h->stage_x) (void)hipFree(h->stage_x);
-  if (h->stage_codes) (void)hipFree(h->stage_codes);
-  if (h->stage_out) (void)hipFree(h->stage_out);
+  host_pipe_destroy(h->pipe);
   for (auto& e : h->ev_pool) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
@@ -1364,7 +1431,8 @@ static const f32x4* small_stream_at(const qinco_handle_s* h, int m, bool body) {
   return h->small_stream + frags * kSmallWaves * 64;
 }
 
-static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool decode = false, const PreselJob* pj = nullptr) {
+static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool decode = false, const PreselJob* pj = nullptr,
+                      bool* did_select = nullptr) {
   const bool unfolded = decode && h->dec_inst;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->prof) {   // the bracket covers xproj + mlp: all the work the algorithmic FLOP count stands for
@@ -1421,6 +1489,8 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
   }
 #endif
   const int nt = decode ? 0 : small_nt(h, a.R, false);
+  if (nt > 0 || !h->sel_inst || decode) a.sel_T = 0;   // (the epilogue selection lives in the 128-row encode kernel)
+  if (did_select) *did_select = a.sel_T > 0;
   if (nt > 0) {   // small launch: workgroups of 16 nt rows, same head (T + U, relu(P + Q)) and the same products in the same order
     SmallArgs sa{};
     sa.wstream = small_stream_at(h, m, true);
@@ -1441,7 +1511,7 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
     sa.dist_out = a.dist_out;
     HIP_TRY(h->small(&sa, 0, nt, st));
   } else {
-    HIP_TRY((unfolded ? h->dec_inst : h->inst)->fn(&a, st));
+    HIP_TRY((unfolded ? h->dec_inst : (a.sel_T > 0 ? h->sel_inst : h->inst))->fn(&a, st));
   }
   if (h->prof) {
     HIP_TRY(hipEventRecord(e1, st));
@@ -1628,20 +1698,32 @@ static int encode_chunk(qinco_handle_s* h, const void* x, int x_dtype, int64_t s
     a.dist_out = h->dist;
     a.add_c = d.qinco1_mode ? 0 : 1;
     a.uproj = h->uproj;
-    if ((rc = launch_mlp(h, a, m, st, false, fused ? &pj : nullptr))) return rc;
     const int C = F * Ae;
     const int T = Fout_cfg < C ? Fout_cfg : C;
-    const size_t lds = (size_t)4 * (((C + T + 3) & ~3) + 2 * SEL_SURV) * sizeof(float);
-    if (lds > 160 * 1024)
-      return fail(QINCO_ERR_UNSUPPORTED, "beam_select: %d candidates per vector do not fit the 160 KiB of LDS", C);
-    if (lds > 64 * 1024 && lds > h->beam_lds_max) {   // above the default dynamic-LDS limit: raise it once
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(beam_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-      h->beam_lds_max = lds;
+    // the step's per-vector top-T in the fused-MLP kernel's epilogue (SELEP instance): a vector's candidates inside one workgroup
+    if (h->sel_inst && C <= 128 && 128 % C == 0) {
+      a.sel_T = T;
+      a.sel_m = m;
+      a.sel_M = M;
+      a.sel_hist_in = h->hist[cur];
+      a.sel_hist_out = h->hist[cur ^ 1];
+      a.sel_xhat_out = h->xhat[cur ^ 1];
     }
-    hipLaunchKernelGGL(beam_select_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, st, h->dist, h->cand, cand_ids,
-                       (long)n, F, Ae, D, T, m, M, h->hist[cur], h->hist[cur ^ 1], h->xhat[cur ^ 1]);
-    HIP_TRY(hipGetLastError());
+    bool selected = false;
+    if ((rc = launch_mlp(h, a, m, st, false, fused ? &pj : nullptr, &selected))) return rc;
+    if (!selected) {
+      const size_t lds = (size_t)4 * (((C + T + 3) & ~3) + 2 * SEL_SURV) * sizeof(float);
+      if (lds > 160 * 1024)
+        return fail(QINCO_ERR_UNSUPPORTED, "beam_select: %d candidates per vector do not fit the 160 KiB of LDS", C);
+      if (lds > 64 * 1024 && lds > h->beam_lds_max) {   // above the default dynamic-LDS limit: raise it once
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(beam_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        h->beam_lds_max = lds;
+      }
+      hipLaunchKernelGGL(beam_select_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, st, h->dist, h->cand, cand_ids,
+                         (long)n, F, Ae, D, T, m, M, h->hist[cur], h->hist[cur ^ 1], h->xhat[cur ^ 1]);
+      HIP_TRY(hipGetLastError());
+    }
     cur ^= 1;
     F = T;
   }
@@ -1793,6 +1875,16 @@ static int ensure_stage(void** p, size_t* cap, size_t need) {
 
 static int check_decode_range(qinco_handle_s* h);
 
+// rows of `rowb` bytes, `stride` apart -> packed
+static void pack_rows(void* dst, const void* src, size_t rowb, size_t stride, int64_t rows) {
+  if (stride == rowb) {
+    std::memcpy(dst, src, rowb * (size_t)rows);
+    return;
+  }
+  for (int64_t r = 0; r < rows; ++r)
+    std::memcpy(reinterpret_cast<char*>(dst) + (size_t)r * rowb, reinterpret_cast<const char*>(src) + (size_t)r * stride, rowb);
+}
+
 extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int64_t stride, int64_t n, void* codes_out,
                                  int code_dtype, float* xhat_out, int flags) {
   int rc = check_common(h, x, codes_out, n, code_dtype, "qinco_encode_host");
@@ -1804,29 +1896,56 @@ extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int
   const size_t rowb = (size_t)h->user.D * esz;
   if (stride == 0) stride = (int64_t)rowb;
   if (stride < (int64_t)rowb) return fail(QINCO_ERR_INVALID, "qinco_encode_host: row stride smaller than a row");
-  // staged in passes of max_batch rows, so a whole database (search_tasks.py:107-116 feeds 1e9 rows) never has to
-  // fit the device twice
+  // passes of max_batch rows, so a whole database (search_tasks.py:107-116 feeds 1e9 rows) never has to fit the device twice
   const int64_t pass = h->d.max_batch;
-  const size_t crow = (size_t)h->d.M * code_size(code_dtype);
+  const size_t crow = (size_t)h->d.M * code_size(code_dtype), orow = (size_t)h->user.D * 4;
   const int64_t cap = n < pass ? n : pass;
+  if ((rc = ensure_scratch(h))) return rc;
+  const size_t need[3] = {(size_t)cap * rowb, (size_t)cap * crow, xhat_out ? (size_t)cap * orow : 0};
+  if ((rc = host_pipe_ensure(&h->pipe, need))) return rc;
+  HostPipe& p = *h->pipe;
   // this call reports its own work only: a flag left behind by an unchecked device-pointer call is dropped
-  if (h->split16) HIP_TRY(hipMemset(h->err_flag, 0, sizeof(int)));
-  if ((rc = ensure_stage(&h->stage_x, &h->stage_x_bytes, (size_t)cap * rowb))) return rc;
-  if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, (size_t)cap * crow))) return rc;
-  if (xhat_out && (rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, (size_t)cap * h->user.D * 4))) return rc;
-  for (int64_t i0 = 0; i0 < n; i0 += pass) {
-    const int64_t nb = n - i0 < pass ? n - i0 : pass;
-    const char* xp = reinterpret_cast<const char*>(x) + i0 * stride;
-    HIP_TRY(hipMemcpy2D(h->stage_x, rowb, xp, (size_t)stride, rowb, (size_t)nb, hipMemcpyHostToDevice));
-    if ((rc = qinco_encode(h, h->stage_x, x_dtype, 0, nb, h->stage_codes, code_dtype, xhat_out ? h->stage_out : nullptr, flags,
-                           nullptr)))
+  if (h->split16) HIP_TRY(hipMemsetAsync(h->err_flag, 0, sizeof(int), p.s_comp));
+  const int64_t P = (n + pass - 1) / pass;
+  auto rows_of = [&](int64_t k) { return k * pass + pass <= n ? pass : n - k * pass; };
+  auto stage_in = [&](int64_t k) -> int {   // pack pass k into its pinned buffer, start its copy to the device
+    const int b = (int)(k & 1);
+    if (k >= 2) HIP_TRY(hipEventSynchronize(p.in_ready[b]));           // the copy of pass k - 2 out of this host buffer has finished
+    pack_rows(p.hbuf[0][b], reinterpret_cast<const char*>(x) + (size_t)(k * pass) * (size_t)stride, rowb, (size_t)stride, rows_of(k));
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(p.s_in, p.comp_done[b], 0));   // ... and the kernels of pass k - 2 have read dx[b]
+    HIP_TRY(hipMemcpyAsync(p.dbuf[0][b], p.hbuf[0][b], (size_t)rows_of(k) * rowb, hipMemcpyHostToDevice, p.s_in));
+    HIP_TRY(hipEventRecord(p.in_ready[b], p.s_in));
+    return 0;
+  };
+  auto finish = [&](int64_t k) -> int {     // the codes (and xhat) of pass k have reached their pinned buffers: hand them to the caller
+    const int b = (int)(k & 1);
+    HIP_TRY(hipEventSynchronize(p.out_ready[b]));
+    std::memcpy(reinterpret_cast<char*>(codes_out) + (size_t)(k * pass) * crow, p.hbuf[1][b], (size_t)rows_of(k) * crow);
+    if (xhat_out) std::memcpy(xhat_out + (size_t)(k * pass) * h->user.D, p.hbuf[2][b], (size_t)rows_of(k) * orow);
+    return 0;
+  };
+  if ((rc = stage_in(0))) return rc;
+  for (int64_t k = 0; k < P; ++k) {
+    const int b = (int)(k & 1);
+    const int64_t nb = rows_of(k);
+    HIP_TRY(hipStreamWaitEvent(p.s_comp, p.in_ready[b], 0));
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(p.s_comp, p.out_ready[b], 0));   // the copy-out of pass k - 2 has read dc[b]
+    if ((rc = qinco_encode(h, p.dbuf[0][b], x_dtype, 0, nb, p.dbuf[1][b], code_dtype, xhat_out ? (float*)p.dbuf[2][b] : nullptr, flags,
+                           p.s_comp)))
       return rc;
-    HIP_TRY(hipMemcpy(reinterpret_cast<char*>(codes_out) + (size_t)i0 * crow, h->stage_codes, (size_t)nb * crow,
-                      hipMemcpyDeviceToHost));
-    if (xhat_out)
-      HIP_TRY(hipMemcpy(xhat_out + (size_t)i0 * h->user.D, h->stage_out, (size_t)nb * h->user.D * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipEventRecord(p.comp_done[b], p.s_comp));
+    HIP_TRY(hipStreamWaitEvent(p.s_out, p.comp_done[b], 0));
+    if (k >= 2) HIP_TRY(hipEventSynchronize(p.out_ready[b]));   // (finish(k - 2) ran already: the host buffer is free; keeps the order explicit)
+    HIP_TRY(hipMemcpyAsync(p.hbuf[1][b], p.dbuf[1][b], (size_t)nb * crow, hipMemcpyDeviceToHost, p.s_out));
+    if (xhat_out) HIP_TRY(hipMemcpyAsync(p.hbuf[2][b], p.dbuf[2][b], (size_t)nb * orow, hipMemcpyDeviceToHost, p.s_out));
+    HIP_TRY(hipEventRecord(p.out_ready[b], p.s_out));
+    if (k + 1 < P && (rc = stage_in(k + 1))) return rc;   // ... under the kernels of pass k
+    if (k >= 1 && (rc = finish(k - 1))) return rc;
   }
-  return h->split16 ? check_decode_range(h) : QINCO_OK;   // (the split form's overflow flag; the copies above have synchronised)
+  if ((rc = finish(P - 1))) return rc;
+  if (!h->split16) return QINCO_OK;
+  HIP_TRY(hipStreamSynchronize(p.s_comp));
+  return check_decode_range(h);   // (the split form's overflow flag)
 }
 
 // The range flag is sticky on the device: import_codes_kernel raises it (and decodes the offending code as 0), the
@@ -1861,17 +1980,44 @@ extern "C" int qinco_decode_host(qinco_handle h, const void* codes, int code_dty
   const size_t orow = (size_t)h->user.D * 4;
   const int64_t pass = kDecodeChunk;
   const int64_t cap = n < pass ? n : pass;
-  if ((rc = ensure_stage(&h->stage_codes, &h->stage_codes_bytes, (size_t)cap * crow))) return rc;
-  if ((rc = ensure_stage((void**)&h->stage_out, &h->stage_out_bytes, (size_t)cap * orow))) return rc;
+  const size_t need[3] = {0, (size_t)cap * crow, (size_t)cap * orow};
+  if ((rc = host_pipe_ensure(&h->pipe, need))) return rc;
+  if ((rc = ensure_decode_scratch(h, cap))) return rc;
+  HostPipe& p = *h->pipe;
   // this call reports its own codes only: a flag left behind by an unchecked device-pointer decode is dropped
-  HIP_TRY(hipMemset(h->err_flag, 0, sizeof(int)));
-  for (int64_t i0 = 0; i0 < n; i0 += pass) {
-    const int64_t nb = n - i0 < pass ? n - i0 : pass;
-    HIP_TRY(hipMemcpy(h->stage_codes, reinterpret_cast<const char*>(codes) + (size_t)i0 * crow, (size_t)nb * crow,
-                      hipMemcpyHostToDevice));
-    if ((rc = qinco_decode(h, h->stage_codes, code_dtype, nb, h->stage_out, flags, nullptr))) return rc;
-    HIP_TRY(hipMemcpy(out + (size_t)i0 * h->user.D, h->stage_out, (size_t)nb * orow, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemsetAsync(h->err_flag, 0, sizeof(int), p.s_comp));
+  const int64_t P = (n + pass - 1) / pass;
+  auto rows_of = [&](int64_t k) { return k * pass + pass <= n ? pass : n - k * pass; };
+  auto stage_in = [&](int64_t k) -> int {
+    const int b = (int)(k & 1);
+    if (k >= 2) HIP_TRY(hipEventSynchronize(p.in_ready[b]));
+    std::memcpy(p.hbuf[1][b], reinterpret_cast<const char*>(codes) + (size_t)(k * pass) * crow, (size_t)rows_of(k) * crow);
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(p.s_in, p.comp_done[b], 0));
+    HIP_TRY(hipMemcpyAsync(p.dbuf[1][b], p.hbuf[1][b], (size_t)rows_of(k) * crow, hipMemcpyHostToDevice, p.s_in));
+    HIP_TRY(hipEventRecord(p.in_ready[b], p.s_in));
+    return 0;
+  };
+  auto finish = [&](int64_t k) -> int {
+    const int b = (int)(k & 1);
+    HIP_TRY(hipEventSynchronize(p.out_ready[b]));
+    std::memcpy(out + (size_t)(k * pass) * h->user.D, p.hbuf[2][b], (size_t)rows_of(k) * orow);
+    return 0;
+  };
+  if ((rc = stage_in(0))) return rc;
+  for (int64_t k = 0; k < P; ++k) {
+    const int b = (int)(k & 1);
+    const int64_t nb = rows_of(k);
+    HIP_TRY(hipStreamWaitEvent(p.s_comp, p.in_ready[b], 0));
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(p.s_comp, p.out_ready[b], 0));
+    if ((rc = qinco_decode(h, p.dbuf[1][b], code_dtype, nb, (float*)p.dbuf[2][b], flags, p.s_comp))) return rc;
+    HIP_TRY(hipEventRecord(p.comp_done[b], p.s_comp));
+    HIP_TRY(hipStreamWaitEvent(p.s_out, p.comp_done[b], 0));
+    HIP_TRY(hipMemcpyAsync(p.hbuf[2][b], p.dbuf[2][b], (size_t)nb * orow, hipMemcpyDeviceToHost, p.s_out));
+    HIP_TRY(hipEventRecord(p.out_ready[b], p.s_out));
+    if (k + 1 < P && (rc = stage_in(k + 1))) return rc;
+    if (k >= 1 && (rc = finish(k - 1))) return rc;
   }
+  if ((rc = finish(P - 1))) return rc;
   return check_decode_range(h);
 }
 

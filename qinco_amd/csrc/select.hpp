@@ -187,6 +187,34 @@ QINCO_DEV bool wave_select_smallest(const float* dv, int C, int T, unsigned long
   return true;
 }
 
+// The T smallest of dv[0..C) (LDS, wave-private; consumed), ascending, ties -> lower index: their flat indices into sel[0..T) (LDS).
+// The selection of QINCoInferenceStepEncoder.forward's topk(F_out) (qinco_inference.py:200) as beam_select_kernel and the fused
+// epilogue of mlp_kernel (SELEP) both run it: threshold-and-compact, or -- T == 1 (one arg-min round is already minimal), more
+// than 64 survivors, massive ties -- T rounds of arg-min.
+QINCO_DEV void wave_top_t(float* dv, int C, int T, unsigned long long* surv, int* sel, int lane) {
+  int rank, index;
+  if (T > 1 && wave_select_smallest(dv, C, T, surv, lane, rank, index)) {
+    if (rank >= 0) sel[rank] = index;
+  } else {
+    for (int t = 0; t < T; ++t) {
+      float bv = __builtin_inff();
+      int bi = 0x7fffffff;
+      for (int k = lane; k < C; k += 64) {  // k ascends: strict < keeps the lowest index
+        const float v = dv[k];
+        const bool take = v < bv;
+        bv = take ? v : bv;
+        bi = take ? k : bi;
+      }
+      wave_argmin(bv, bi);
+      if (bi == 0x7fffffff) bi = 0;           // only NaN / +inf left: degenerate, keep in range
+      if ((bi & 63) == lane) dv[bi] = __builtin_inff();
+      if (lane == 0) sel[t] = bi;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // wave_sort64 of GP independent values, one compare-exchange step at a time across all of them (a dependent DPP chain needs
 // wait states after every step; GP chains interleaved need none)
 template <int K, int J, int GP>

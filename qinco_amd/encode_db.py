@@ -59,20 +59,33 @@ def _dist_info(dist):
     return 0, 1
 
 
+def compact_code_dtype(K: int, cols: int, M: int):
+    """The narrowest integer type that holds a code row: a byte per code when K <= 256 and there is no IVF column (cols == M),
+    else int32 (an IVF id goes up to 2^24).  The reference keeps int64 everywhere (8 B per code): at 10^9 vectors x 8 codes that is
+    64 GB per copy for an 8 GB payload."""
+    return np.dtype(np.uint8) if (K <= 256 and cols == M) else np.dtype(np.int32)
+
+
 def encode_shard(model: Callable, db_vecs, start: int, end: int, batch: int = 65536,
-                 to_device: Optional[Callable] = None, sink: Optional[Callable] = None, pipeline: bool = True) -> np.ndarray:
-    """Encode rows [start, end) in batches: codes (end-start, M) int64 in file order (search_tasks.py:107-116).
+                 to_device: Optional[Callable] = None, sink: Optional[Callable] = None, pipeline: bool = True,
+                 code_dtype=np.int64, keep: bool = True, K: Optional[int] = None, M: Optional[int] = None) -> Optional[np.ndarray]:
+    """Encode rows [start, end) in batches: codes (end-start, M) in file order (search_tasks.py:107-116).
     `model(x, step="encode")` returns (M, n) like the reference's model object.  sink(codes_batch): called with every
     batch's codes as they arrive (the part-file writer compresses them while the GPU encodes the next batch).
 
+    Memory: every batch is narrowed as it arrives and stored into ONE preallocated (rows, cols) array -- uint8 when K <= 256 (int32
+    with an IVF column; K, M given) -- so a shard costs `cols` bytes per vector on the host while it is encoded; `code_dtype` is
+    what is RETURNED (np.int64 = the reference's type, widened once at the end; "compact" = as stored).  keep=False: nothing is
+    retained, every batch goes to `sink` only (a part-file-only encode of a billion vectors holds one batch), returns None.
+
     pipeline: the host work either side of the model call -- paging the next batch in from the memmap, and the transpose /
-    int64 widening / sink of the previous batch's codes -- runs on two helper threads while the model call (which releases
+    narrowing / sink of the previous batch's codes -- runs on two helper threads while the model call (which releases
     the GIL inside libqinco_hip) keeps the GPU busy.  The reference does all of it serially (search_tasks.py:107-116), which
     is free next to its CPU encode and 15 % of the wall clock next to a qinco2-S encode on the GPU.  Same results, same order."""
     bounds = [(i0, min(end, i0 + batch)) for i0 in range(start, end, batch)]
-    parts: list = [None] * len(bounds)
+    state = {"out": None}
     if not bounds:
-        return np.zeros((0, 0), np.int64)
+        return np.zeros((0, 0), np.int64) if keep else None
 
     def load(k):
         i0, i1 = bounds[k]
@@ -80,38 +93,67 @@ def encode_shard(model: Callable, db_vecs, start: int, end: int, batch: int = 65
         if to_device is not None:
             return to_device(xb)
         if isinstance(xb, np.memmap) or (isinstance(xb, np.ndarray) and not xb.flags.owndata and pipeline):
-            xb = np.ascontiguousarray(xb)          # page the rows in here, not inside the timed model call
-        return xb
+            xb = np.array(xb, copy=True)           # page the rows in HERE (a contiguous memmap slice is a view until it is copied),
+        return xb                                  # not inside the timed model call
 
-    def finish(k, codes):
+    def finish(k, codes, ready):
+        if ready is not None:
+            ready.synchronize()                    # the encode that produced `codes` (enqueued on the CALLER's stream) has finished
         codes = codes.T
         if hasattr(codes, "cpu"):
             codes = codes.cpu().numpy()
-        parts[k] = np.ascontiguousarray(codes, dtype=np.int64)
+        if state["out"] is None:
+            cols = codes.shape[1]
+            narrow = compact_code_dtype(K, cols, M) if (K is not None and M is not None) else np.dtype(np.int64)
+            state["narrow"] = narrow
+            if keep:
+                state["out"] = np.empty((end - start, cols), narrow)
+        narrow = state["narrow"]
+        if narrow.itemsize < 8 and codes.size and (int(codes.max()) > np.iinfo(narrow).max or int(codes.min()) < 0):
+            raise ValueError(f"a code does not fit {narrow} (K={K})")
+        small = np.ascontiguousarray(codes, dtype=narrow)
+        if keep:
+            i0, i1 = bounds[k]
+            state["out"][i0 - start: i1 - start] = small
         if sink is not None:
-            sink(parts[k])
+            sink(small)
+
+    def event_of(codes):
+        """Device-path encodes are asynchronous on the caller's current stream; the helper thread that copies them to the host
+        must wait for THAT stream (its own current stream is the default one)."""
+        if hasattr(codes, "is_cuda") and codes.is_cuda:
+            import torch
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(codes.device))
+            return ev
+        return None
 
     if not pipeline or len(bounds) == 1:
         for k in range(len(bounds)):
-            finish(k, model(load(k), step="encode"))
-        return np.concatenate(parts)
-    import concurrent.futures as cf
-    with cf.ThreadPoolExecutor(max_workers=1) as loader, cf.ThreadPoolExecutor(max_workers=1) as finisher:   # one each: order kept
-        # (to_device runs on the caller's thread: the current CUDA device is per-thread state, and `.cuda()` in a helper
-        # thread would land on device 0)
-        prefetch = to_device is None
-        nxt = loader.submit(load, 0) if prefetch else None
-        done = None
-        for k in range(len(bounds)):
-            xb = nxt.result() if prefetch else load(k)
-            if prefetch and k + 1 < len(bounds):
-                nxt = loader.submit(load, k + 1)
-            codes = model(xb, step="encode")
-            if done is not None:
-                done.result()                       # (surfaces exceptions of the previous batch's post-processing)
-            done = finisher.submit(finish, k, codes)
-        done.result()
-    return np.concatenate(parts)
+            finish(k, model(load(k), step="encode"), None)
+    else:
+        import concurrent.futures as cf
+        with cf.ThreadPoolExecutor(max_workers=1) as loader, cf.ThreadPoolExecutor(max_workers=1) as finisher:   # one each: order kept
+            # (to_device runs on the caller's thread: the current CUDA device is per-thread state, and `.cuda()` in a helper
+            # thread would land on device 0)
+            prefetch = to_device is None
+            nxt = loader.submit(load, 0) if prefetch else None
+            done = None
+            for k in range(len(bounds)):
+                xb = nxt.result() if prefetch else load(k)
+                if prefetch and k + 1 < len(bounds):
+                    nxt = loader.submit(load, k + 1)
+                codes = model(xb, step="encode")
+                if done is not None:
+                    done.result()                       # (surfaces exceptions of the previous batch's post-processing)
+                done = finisher.submit(finish, k, codes, event_of(codes))
+            done.result()
+    if not keep:
+        return None
+    out = state["out"]
+    if isinstance(code_dtype, str) and code_dtype == "compact":
+        return out
+    return out if out.dtype == np.dtype(code_dtype) else out.astype(code_dtype)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -284,7 +326,7 @@ def _barrier(dist, device=None):
 
 def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D: int, batch: int = 65536,
                     dist=None, gather: bool = False, to_device: Optional[Callable] = None, device=None,
-                    writer_threads: int = 8, resume: bool = False):
+                    writer_threads: int = 8, resume: bool = False, code_dtype=np.int64, keep: bool = True):
     """Reference-compatible database encode.  Returns this rank's codes; with gather=True rank 0 returns the
     whole (N, M) code matrix collected with one collective (other ranks: their own shard).  `device`: where the
     collective's buffers live (default: this rank's current GPU under backend "nccl", the host under "gloo").
@@ -294,11 +336,17 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
     `writer_threads` threads while the shard is still being encoded (PartFileWriter; 0 = numpy's single-threaded
     np.savez_compressed at the end, the reference's way -- same format either way).
 
-    resume=True: a rank whose part file is already there with the right number of rows loads it instead of encoding its shard
-    again (the reference's encode_database has no resume: a crashed rank costs the whole job; part files are written under a
-    temporary name and renamed when complete, so one that exists is whole).  Every rank still takes part in the barriers and in
-    the gather."""
+    Host memory (the north_star's 10^9-vector job): codes are held as uint8 (int32 with an IVF column) from the GPU to the gather
+    and widened to the file format's int64 only chunk by chunk inside the part-file writer.  code_dtype = what is RETURNED:
+    np.int64 (default, the reference's type: 8 B per code, fine at 10^6), "compact" (as held: M bytes per vector; the gathered
+    matrix on rank 0 too).  keep=False: nothing is returned or retained (part files only; not with gather or writer_threads=0).
+
+    resume=True: a rank whose part file is already there -- right number of rows AND code columns, next to an `<output>` header
+    written for the same n_parts, K, M, D -- loads it instead of encoding its shard again (the reference's encode_database has no
+    resume: a crashed rank costs the whole job; part files are written under a temporary name and renamed when complete, so one
+    that exists is whole).  Every rank still takes part in the barriers and in the gather."""
     assert output.endswith(".npz")
+    assert keep or (not gather and writer_threads > 0), "keep=False writes part files only"
     base = output[:-4]
     rank, world = _dist_info(dist)
     if world > 1:
@@ -306,7 +354,8 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
     start, end = shard_bounds(len(db_vecs), world, rank)
     state = {"writer": None}
     part = base + f".part_{rank}.npz"
-    done = _load_part(part, end - start) if resume else None
+    done = _load_part(part, end - start, (M, M + 1), _header_matches(output, world, K, M, D)) if resume else None
+    compact = isinstance(code_dtype, str) and code_dtype == "compact"
 
     def sink(c):   # created with the first batch: the number of code columns is the model's business (M + 1 with an IVF column)
         if state["writer"] is None:
@@ -314,11 +363,16 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
         state["writer"].add(c)
     if done is not None:
         codes = done
+        if keep and (compact or gather):
+            codes = codes.astype(compact_code_dtype(K, codes.shape[1], M))
+        elif not keep:
+            codes = None
     else:
-        codes = encode_shard(model, db_vecs, start, end, batch, to_device, sink if (writer_threads > 0 and end > start) else None)
+        codes = encode_shard(model, db_vecs, start, end, batch, to_device, sink if (writer_threads > 0 and end > start) else None,
+                             code_dtype="compact", keep=keep, K=K, M=M)
     writer = state["writer"]
-    if codes.size == 0:
-        codes = np.zeros((0, M), np.int64)
+    if codes is not None and codes.size == 0:
+        codes = np.zeros((0, M), compact_code_dtype(K, M, M))
     if world > 1:
         _barrier(dist, device)
     if rank == 0:
@@ -328,57 +382,83 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
         np.savez_compressed(output, n_parts=world, K=K, M=M, D=D)
     if writer is not None:
         writer.close()
-    elif done is None:
+    elif done is None and keep:
         tmp = part + ".tmp.npz"      # (np.savez appends .npz to other suffixes)
-        np.savez_compressed(tmp, codes=codes)
+        np.savez_compressed(tmp, codes=codes.astype(np.int64))
         os.replace(tmp, part)
     if world > 1:
         _barrier(dist, device)
+    if not keep:
+        return None
     if gather:
-        return gather_codes(codes, len(db_vecs), dist, device=device)
-    return codes
+        codes = gather_codes(codes, len(db_vecs), dist, device=device, code_dtype="compact")
+    if compact or codes.dtype == np.dtype(code_dtype):
+        return codes
+    return codes.astype(code_dtype)
 
 
-def _load_part(path: str, rows: int) -> Optional[np.ndarray]:
-    """The codes of a finished part file, or None (missing, unreadable, or of another shard size)."""
-    if not os.path.exists(path):
+def _header_matches(output: str, n_parts: int, K: int, M: int, D: int) -> bool:
+    """resume: the `<output>` header of an earlier run describes the same job (a part file of another model or another world size
+    with the same shard length must not be taken for this run's)."""
+    try:
+        info = np.load(output)
+        return all(int(info[k]) == v for k, v in (("n_parts", n_parts), ("K", K), ("M", M), ("D", D)))
+    except Exception:
+        return False
+
+
+def _load_part(path: str, rows: int, cols=None, header_ok: bool = True) -> Optional[np.ndarray]:
+    """The codes of a finished part file, or None (missing, unreadable, of another shard size or column count, or without a
+    matching header)."""
+    if not header_ok or not os.path.exists(path):
         return None
     try:
         codes = np.load(path)["codes"]
     except Exception:      # a truncated / foreign file: encode the shard again
         return None
-    return codes if codes.ndim == 2 and len(codes) == rows else None
+    if codes.ndim != 2 or len(codes) != rows or (cols is not None and codes.shape[1] not in cols):
+        return None
+    return codes
 
 
-def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None) -> Optional[np.ndarray]:
-    """One gather of the per-rank code shards to rank 0.  Shards are padded to the longest one
-    (the last rank holds the remainder) so a single fixed-size collective moves everything; codes travel as
-    uint8 when K <= 256 (M bytes per vector).  Returns (N, M) int64 on rank 0, the local shard elsewhere."""
+def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None, code_dtype=np.int64) -> Optional[np.ndarray]:
+    """The per-rank code shards to rank 0: every rank sends its shard once, rank 0 receives each one straight into
+    its rows of ONE preallocated (N, M) matrix of the wire type -- uint8 when every code is below 256 (M bytes per vector), else
+    the shards' own type -- so the collective costs rank 0 one copy of the payload (8 GB at 10^9 x 8 codes), not a padded bucket
+    per rank plus int64 copies of all of them.  Shards may differ in length (the last rank holds the remainder): point-to-point
+    transfers (grouped on RCCL) instead of a fixed-size gather.  Returns (N, M) on rank 0 -- `code_dtype` np.int64 (the reference's
+    type) or "compact" (the wire type) -- and the local shard elsewhere."""
     rank, world = _dist_info(dist)
+    compact = isinstance(code_dtype, str) and code_dtype == "compact"
     if world == 1:
-        return codes_local
+        return codes_local if compact else codes_local.astype(code_dtype, copy=False)
     import torch
     device = _comm_device(dist, device)
     M = codes_local.shape[1]
     small = codes_local.size == 0 or int(codes_local.max()) < 256
-    flag = torch.tensor([1 if small else 0], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    wire = np.uint8 if int(flag.item()) == 1 else np.int64
-    longest = max(shard_bounds(db_size, world, r)[1] - shard_bounds(db_size, world, r)[0] for r in range(world))
-    buf = np.zeros((longest, M), wire)
-    buf[: len(codes_local)] = codes_local.astype(wire)
-    t = torch.from_numpy(buf)
+    wide = 0 if small else (1 if codes_local.dtype.itemsize <= 4 and int(codes_local.max()) < 2 ** 31 else 2)
+    flag = torch.tensor([wide], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    wire = (np.uint8, np.int32, np.int64)[int(flag.item())]
+    mine = torch.from_numpy(np.ascontiguousarray(codes_local, dtype=wire))
     if device is not None:
-        t = t.to(device)
-    out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-    dist.gather(t, out, dst=0)
+        mine = mine.to(device)
     if rank != 0:
+        if len(mine):
+            dist.send(mine, dst=0)
         return codes_local
-    parts = []
-    for r in range(world):
+    full = torch.empty((db_size, M), dtype=mine.dtype, device=mine.device)
+    s0, e0 = shard_bounds(db_size, world, 0)
+    full[s0:e0] = mine
+    reqs = []
+    for r in range(1, world):
         s, e = shard_bounds(db_size, world, r)
-        parts.append(out[r][: e - s].cpu().numpy().astype(np.int64))
-    return np.concatenate(parts)
+        if e > s:
+            reqs.append(dist.irecv(full[s:e], src=r))
+    for q in reqs:
+        q.wait()
+    out = full.cpu().numpy()
+    return out if compact else out.astype(code_dtype, copy=False)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -403,6 +483,8 @@ class EncodedDBIterator:
             db_codes = np.load(self.part_base_path + f".part_{i_part}.npz")["codes"]
             bs = batch_size or len(db_codes)
             self.part_n_batches = math.ceil(len(db_codes) / bs) if bs else 0
+            # (the reference's own estimate, on purpose: n_parts x the length of the part being read, search_utils.py:62 -- exact
+            # only for equal shards; callers that need the count use load_all() or the header)
             self.n_samples = self.n_parts * len(db_codes)
             for ib in range(0, len(db_codes), bs or 1):
                 batch = db_codes[ib: ib + bs]

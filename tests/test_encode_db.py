@@ -247,3 +247,37 @@ def test_numa_cpu_set_of_a_gpu_from_sysfs(tmp_path, monkeypatch):
     (tmp_path / "bus/pci/devices/0000:c1:00.0/numa_node").write_text("-1\n")     # single-node box
     assert affinity.numa_cpus_of_gpu(0, sysfs=str(tmp_path)) is None
     assert affinity.bind_to_gpu_numa(0) is None or isinstance(affinity.bind_to_gpu_numa(0), dict)
+
+
+def test_host_memory_of_a_50_million_vector_encode(tmp_path):
+    """The north_star's job is 10^9 vectors x 8 codes: an 8 GB payload.  Codes must stay bytes on the host from the model call to the
+    gathered matrix (the reference's int64 everywhere would be 64 GB per copy, and the round-3 code held two such copies on rank 0).
+    A 50-million-vector encode with a stand-in model in a process of its own: peak resident memory stays near ONE copy of the
+    byte payload (400 MB) + a few batches, far below the 3.2 GB of a single int64 copy; the part file still holds int64 codes."""
+    import subprocess
+    script = r'''
+import os, resource, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from qinco_amd.encode_db import EncodedDBIterator, encode_database
+N, M, B = 50_000_000, 8, 1_000_000
+class DB:                      # (N, 4) uint8 rows made on demand: the input side holds one batch
+    def __len__(self): return N
+    def __getitem__(self, sl):
+        i = np.arange(sl.start, sl.stop, dtype=np.int64)
+        return ((i[:, None] * np.array([1, 3, 5, 7])) & 255).astype(np.uint8)
+def model(x, step):            # (M, n) int64 like the reference's model object
+    s = x.astype(np.int64).sum(axis=1)
+    return ((s[None, :] + np.arange(M)[:, None] * 17) & 255)
+base = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+codes = encode_database(model, DB(), os.path.join(sys.argv[2], "db.npz"), K=256, M=M, D=4, batch=B, code_dtype="compact", gather=True)
+peak = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+assert codes.dtype == np.uint8 and codes.shape == (N, M)
+it = EncodedDBIterator(os.path.join(sys.argv[2], "db.npz"), K=256, M=M, D=4)
+first = next(it.iter(1000))
+assert first.dtype == np.int64 and np.array_equal(first, codes[:1000])
+print("PEAK_MB", (peak - base) / 1024.0)
+'''
+    r = subprocess.run([sys.executable, "-c", script, str(ROOT), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    peak_mb = float(r.stdout.split("PEAK_MB")[1])
+    assert peak_mb < 1200, f"peak resident growth {peak_mb:.0f} MB for a 400 MB byte payload"

@@ -423,6 +423,69 @@ def test_fused_preselection_launch_is_bit_identical_to_the_two_kernels(model, D,
     plain.close()
 
 
+@pytest.mark.parametrize("shape", ["qinco2-S", "qinco2-L", "qinco1", "tiny_proj", "tiny_id", "qinco2-S_d96", "qinco2-S_d768", "qinco2-L_d768"])
+def test_small_launch_form_is_bit_identical_to_the_128_row_kernels(shape):
+    """Launches below ~one 128-row workgroup per CU run on the small-launch form of the fused MLP (csrc/mlp_small_kernel.hpp:
+    workgroups of 16 * NT rows, eight waves splitting the output features, activations through LDS, every decode step in one
+    launch).  It adds the same products in the same order as mlp_kernel -- the 16 x 16 x 4 MFMA contracts a block's features in
+    the order the 32 x 32 x 2 fragments do -- so decode output and greedy codes must be the SAME BITS as a handle created with
+    no_small_launch (and decode through the folded instance, the association the small form uses), at row counts around every
+    tile and NT boundary."""
+    import torch
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    from qinco_amd.config import QincoConfig, preset
+    cfg = {"qinco2-S": lambda: preset("qinco2-S", D=128, M=4, B=8), "qinco2-L": lambda: preset("qinco2-L", D=128, M=3, L=3, B=8),
+           "qinco1": lambda: preset("qinco1", D=128, M=3, L=3),
+           "tiny_proj": lambda: QincoConfig(D=32, M=4, K=256, L=2, de=64, dh=96, A=8, B=4),
+           "tiny_id": lambda: QincoConfig(D=32, M=4, K=256, L=1, de=None, dh=64, A=8, B=4),
+           "qinco2-S_d96": lambda: preset("qinco2-S", D=96, M=3, B=4), "qinco2-S_d768": lambda: preset("qinco2-S", D=768, M=3, B=4),
+           "qinco2-L_d768": lambda: preset("qinco2-L", D=768, M=3, L=2, B=4)}[shape]()
+    sd = synth_state_dict(cfg, 4242)
+    nmax = 5000
+    x = torch.from_numpy(synth_vectors(cfg, sd, nmax, seed=43)).cuda()
+    rs = np.random.RandomState(44)
+    codes = torch.from_numpy(np.stack([rs.randint(0, k, size=nmax) for k in cfg.K_vals], axis=1).astype(np.int32)).cuda()
+    small = QincoEngine(cfg, sd, max_batch=8192)
+    big = QincoEngine(cfg, sd, max_batch=8192, diagnostics={"no_small_launch": True, "decode_folded": True})
+    for n in (1, 15, 16, 17, 48, 100, 1024, 4095, 4097, 5000):
+        ds, db = small.decode(codes[:n]).cpu().numpy(), big.decode(codes[:n]).cpu().numpy()
+        assert np.array_equal(ds.view(np.uint32), db.view(np.uint32)), (shape, n)
+    small.set_beam(cfg.A, 1)      # greedy: n * A rows per step, the small form's encode-step kernel
+    big.set_beam(cfg.A, 1)
+    for n in (1, 7, 64, 1000):
+        cs, hs = small.encode(x[:n], return_xhat=True)
+        cb, hb = big.encode(x[:n], return_xhat=True)
+        assert torch.equal(cs, cb) and torch.equal(hs, hb), (shape, n)
+    small.close()
+    big.close()
+
+
+@pytest.mark.parametrize("shape,A,B", [("qinco2-S", 16, 8), ("qinco2-S", 16, 4), ("qinco2-S", 16, 2), ("qinco2-S", 8, 16), ("qinco2-S", 32, 4),
+                                       ("tiny_id", 8, 4), ("tiny_id", 8, 16), ("tiny_id", 4, 8), ("tiny_id", 16, 1)])
+def test_epilogue_selection_is_bit_identical_to_beam_select(shape, A, B):
+    """Identity-projection models whose F * A candidates per vector fit a 128-row workgroup take the step's top-B inside the
+    fused-MLP kernel's epilogue (csrc/mlp_kernel.hpp SELEP): no candidate / distance write-back, no beam_select launch.  Same
+    distances, same selection code (select.hpp wave_top_t): codes and tracked reconstructions must equal the two-kernel form bit for
+    bit -- at sizes where the last workgroup is partly empty, with heavy ties (duplicated vectors), and with the beam still
+    growing in the first steps (F < B)."""
+    import torch
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    from qinco_amd.config import QincoConfig, preset
+    cfg = preset("qinco2-S", D=128, M=4, A=A, B=B) if shape == "qinco2-S" else QincoConfig(D=32, M=4, K=256, L=2, de=None, dh=64, A=A, B=B)
+    sd = synth_state_dict(cfg, 777)
+    x = synth_vectors(cfg, sd, 20000, seed=78)
+    x[100:200] = x[0:100]            # duplicated rows: identical candidate distances
+    xd = torch.from_numpy(x).cuda()
+    fused = QincoEngine(cfg, sd, max_batch=20000)
+    plain = QincoEngine(cfg, sd, max_batch=20000, diagnostics={"no_epilogue_select": True})
+    for n in (20000, 4097, 2049):      # (large enough for the 128-row kernels: below, the small-launch form serves the step)
+        cf, hf = fused.encode(xd[:n], return_xhat=True)
+        cp, hp = plain.encode(xd[:n], return_xhat=True)
+        assert torch.equal(cf, cp) and torch.equal(hf, hp), n
+    fused.close()
+    plain.close()
+
+
 @pytest.mark.parametrize("model,D", [("qinco2-S", 128), ("qinco2-M", 128), ("qinco1", 128)])
 def test_codes_do_not_depend_on_max_batch(model, D):
     """The same vectors through handles of different max_batch take different kernels (small passes: cooperative / fused

@@ -198,13 +198,22 @@ def test_bench_driver_line_carries_the_metric_grid():
     assert "error" not in c1, c1
     n_same, n_all = (int(v) for v in c1["greedy_rows_equal_to_oracle"].split("/"))
     assert n_all == 256 and n_same >= 254 and c1["cpu_baseline"]["value"] > 0 and c1["gpu_over_cpu"] > 10
-    assert 0.5 < c1["roofline"]["frac_executed"] <= 1.0
+    assert 0.5 < c1["roofline"]["frac"] <= 1.0 and c1["roofline"]["frac"] <= c1["roofline"]["frac_algorithmic"] + 1e-9
+    for rows in (1024, 12288, 16384):      # decode at the reference's call sizes rides on the c1 and qinco2_S legs
+        d = c1[f"decode_batch_{rows}"]
+        assert d["rows_per_call"] == rows and d["value"] > 0 and 0 < d["roofline"]["frac"] <= 1.0
+    assert c1["decode_batch_12288"]["roofline"]["frac"] > 0.6 and "weight_stream_gb_per_s" in c1["decode_batch_1024"]
+    par = rec["parity"]
+    for key in ("C1", "C2", "C2_beam1", "C3", "C4"):
+        assert "error" not in par[key], par[key]
+        same, rows = (int(v) for v in par[key]["codes_equal_to_reference"].split("/"))
+        assert rows > 0 and same >= rows - 1 and par[key]["decode_max_rel_err"] < 1e-5, par[key]
     for k in ("qinco2_S", "ivf_qinco2_S"):
         assert "error" not in rec[k] and rec[k]["value"] > 0, rec[k]
     assert rec["ivf_qinco2_S"]["ivf"]["ivf_K"] == 1 << 20 and not rec["ivf_qinco2_S"]["ivf"]["fell_back_to_fp32_table"]
     for k, M, D in (("c3", 16, 128), ("c4", 8, 768)):
         assert "error" not in rec[k], rec[k]
-        assert rec[k]["M"] == M and rec[k]["D"] == D and rec[k]["value"] > 0 and 0.5 < rec[k]["roofline"]["frac_executed"] <= 1.0
+        assert rec[k]["M"] == M and rec[k]["D"] == D and rec[k]["value"] > 0 and 0.5 < rec[k]["roofline"]["frac"] <= 1.0
     for key in ("encode_db_bvecs", "encode_db_bvecs_qinco2S"):
         db = rec[key]
         assert "error" not in db, db
@@ -219,8 +228,10 @@ def test_bench_line_schema_single_gpu():
               "vs_baseline", "dtype", "data", "config", "roofline", "decode", "mse", "batch_1024"):
         assert k in rec, k
     rf = rec["roofline"]
-    assert rf["bound"] == "mfma" and 0 < rf["frac_executed"] <= 1.0 and rf["frac_executed"] <= rf["frac"] + 1e-9
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] <= 1.0 and rf["frac"] <= rf["frac_algorithmic"] + 1e-9
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert rec["decode"]["value"] > rec["value"] and 0 < rec["decode"]["roofline"]["frac_executed"] <= 1.0
+    assert rec["decode"]["value"] > rec["value"] and 0 < rec["decode"]["roofline"]["frac"] <= 1.0
+    for rows in (1024, 12288, 16384):
+        assert 0 < rec[f"decode_batch_{rows}"]["roofline"]["frac"] <= 1.0
     assert rec["mse"]["value"] > 0 and rec["mse"]["vectors"] == 2 * 2048
     assert rec["config"]["distinct_vectors_encoded"] == 2 * 2048

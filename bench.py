@@ -232,6 +232,15 @@ def leg_workload(torch, dev, name, steps, batch, oracle_sample=0, decode_sizes=(
            "vectors_per_step": batch, "ms_per_step": dt / steps * 1e3, "A": cfg.A, "B": cfg.B, "M": cfg.M, "D": cfg.D,
            "gflop_per_vector": eng.flops_per_vector("encode") / 1e9,
            "roofline": roofline_dict(prof, dt, kernel="qinco::mlp_kernel (+ xproj)" if cfg.De <= 384 else "qinco::mlp16_kernel")}
+    if decode_sizes:      # the reference's default host batch (qinco_cfg.yaml:38): one encode call per 1024 distinct vectors
+        small = [xs[1][i:i + 1024] for i in range(0, batch, 1024)]
+        eng.encode(small[0], code_dtype=cdt)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for xb in small:
+            eng.encode(xb, code_dtype=cdt)
+        torch.cuda.synchronize(dev)
+        out["batch_1024"] = {"value": batch / (time.perf_counter() - t1), "unit": "vectors/s", "calls": len(small)}
     if decode_sizes:      # decode of these codes at the reference's call sizes (leg_decode_calls)
         codes_all = torch.cat(codes)
         for rows in decode_sizes:
@@ -694,6 +703,9 @@ def extras(torch, dev, args, cfg, sd, eng, out, mine, batches, warm, value, sqer
         eng.set_beam(B=1)
         out["beam1"] = {"value": timed_encode(batches[:min(K, 2)]), "unit": "vectors/s", "A": eng.A, "B": 1,
                         "gflop_per_vector": eng.flops_per_vector("encode") / 1e9}
+        # ... at the reference's host batch: 1024 x A = 16 384 MLP rows per step, the small-launch form's encode-step kernel
+        out["beam1_batch_1024"] = {"value": timed_encode(small), "unit": "vectors/s", "calls": len(small)}
+        out["beam1_batch_1024"]["over_beam1"] = out["beam1_batch_1024"]["value"] / out["beam1"]["value"]
         eng.set_beam(B=cfg.B)
     # ---- the opt-in split-fp16 form of the FFN blocks (include/qinco_hip.h QINCO_CREATE_SPLIT_F16): NOT the headline --
     # `value` above is the fp32 path; this leg re-encodes the same timed batches and counts the code rows that change

@@ -106,9 +106,11 @@ enum {
   QINCO_CREATE_SPLIT_NO_CALIBRATION = 32,  /* skip the create-time comparison with the fp32 instance (below) */
   QINCO_CREATE_NO_PRESEL_FUSION = 64,      /* diagnostics: pre-selection table and xproj as two launches at every launch size */
   QINCO_CREATE_NO_SMALL_LAUNCH = 128,      /* diagnostics: the 128-rows-per-workgroup kernels at every launch size */
-  QINCO_CREATE_NO_EPILOGUE_SELECT = 256    /* diagnostics: candidates and distances always written back, beam_select_kernel always run
-                                              (default: identity-projection models whose F * A candidates per vector fit a workgroup
-                                              take the per-vector top-B in the fused-MLP kernel's epilogue, csrc/mlp_kernel.hpp SELEP) */
+  QINCO_CREATE_EPILOGUE_SELECT = 256       /* opt-in (measured slower, off by default): identity-projection models whose F * A candidates per
+                                              vector fit a 128-row workgroup take the step's per-vector top-B in the fused-MLP kernel's
+                                              epilogue (csrc/mlp_kernel.hpp SELEP) -- no candidate / distance write-back, no beam_select
+                                              launch, bit-identical codes; the longer end of a workgroup's life costs more than the
+                                              write-back it saves: qinco2-S 635 k against 672 k vectors/s */
 };
 
 /* The split form checks itself.  (1) At create, unless QINCO_CREATE_SPLIT_NO_CALIBRATION: the model is also built as an fp32
@@ -262,6 +264,16 @@ QINCO_API int qinco_knn_search_host(qinco_knn knn, const float* db, int64_t n, c
 /* *sum_out = sum_i (a[i] - b[i])^2 over `count` floats on the device (AnyVectMSE.update, qinco/metrics.py:43-50;
  * accumulated in fp64); synchronises `stream`. */
 QINCO_API int qinco_sqerr_sum(const float* a, const float* b, int64_t count, double* sum_out, void* stream);
+
+/* Re-rank of per-query shortlists -- the re-rank stages of run_search_ivf (qinco/search/search_tasks.py:447-472 with the pairwise
+ * look-up decoder's reconstructions, :497-507 with QINCo's): for every query q the distances |xq[q]|^2 + |c|^2 - 2 xq[q].c to ITS ns
+ * candidates cand[q] (compute_batch_distances(..., approx=True), utils.py:349-383), sorted ascending (ties -> the earlier shortlist
+ * position), the first k kept: their shortlist positions, distances, database ids (ids_in (nq, ns) -> ids_out (nq, k)) and code rows
+ * (codes_in (nq, ns, Mc) int32 -> codes_out (nq, k, Mc)).  Every output is optional (NULL).  Device pointers, asynchronous on
+ * `stream`.  ns * 8 + D * 4 bytes of LDS per query: ns <= 16384. */
+QINCO_API int qinco_rerank(const float* xq, const float* cand, int64_t nq, int32_t ns, int32_t D, int32_t k, const int64_t* ids_in,
+                 const int32_t* codes_in, int32_t Mc, int64_t* pos_out, float* dist_out, int64_t* ids_out, int32_t* codes_out,
+                 void* stream);
 
 /* Device self-test of the in-wave sort / top-T selection primitives the table and beam kernels are built on, against a host
  * computation (random data, heavy ties, NaN / inf).  QINCO_OK, or QINCO_ERR_HIP with the first discrepancy in

@@ -12,7 +12,7 @@ X_F32, X_U8 = 0, 1
 CODE_I64, CODE_I32, CODE_U8 = 0, 1, 2
 FLAG_NORMALISED = 1
 CREATE_SPLIT_F16, CREATE_IVF_FP32, CREATE_TABLE_VALU, CREATE_DECODE_FOLDED, CREATE_TABLE_NO_COOP = 1, 2, 4, 8, 16
-CREATE_SPLIT_NO_CALIBRATION, CREATE_NO_PRESEL_FUSION, CREATE_NO_SMALL_LAUNCH, CREATE_NO_EPILOGUE_SELECT = 32, 64, 128, 256
+CREATE_SPLIT_NO_CALIBRATION, CREATE_NO_PRESEL_FUSION, CREATE_NO_SMALL_LAUNCH, CREATE_EPILOGUE_SELECT = 32, 64, 128, 256
 
 # every symbol include/qinco_hip.h declares (tests check the library exports all of them)
 API_SYMBOLS = [
@@ -20,7 +20,7 @@ API_SYMBOLS = [
     "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_profile_read2", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
     "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
-    "qinco_ivf_last_stats", "qinco_check", "qinco_selftest", "qinco_knn_create", "qinco_knn_destroy", "qinco_knn_search", "qinco_knn_search_host", "qinco_sqerr_sum",
+    "qinco_ivf_last_stats", "qinco_check", "qinco_selftest", "qinco_knn_create", "qinco_knn_destroy", "qinco_knn_search", "qinco_knn_search_host", "qinco_sqerr_sum", "qinco_rerank",
 ]
 
 
@@ -141,6 +141,8 @@ def load() -> C.CDLL:
     lib.qinco_knn_search.argtypes = [vp, vp, i64, vp, i64, C.c_int32, vp, vp, vp]
     lib.qinco_knn_search_host.argtypes = [vp, vp, i64, vp, i64, C.c_int32, vp, vp]
     lib.qinco_sqerr_sum.argtypes = [vp, vp, i64, C.POINTER(dbl), vp]
+    lib.qinco_rerank.argtypes = [vp, vp, i64, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
+    lib.qinco_rerank.restype = C.c_int
     for name in ("qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host"):
         getattr(lib, name).restype = C.c_int
     lib.qinco_last_error.restype = C.c_char_p

@@ -174,34 +174,30 @@ def ensure_instance(D: int, De: int, Dh: int, verbose: bool = False) -> Path | N
     for v in variants:
         so = inst_dir / f"inst_{Dp}_{Dep}_{Dhp}_{P}_{v}.so"
         cmd = [c for c in instance_cmd("hipcc", (Dp, Dep, Dhp, P, v), so, extra=("-DQINCO_INSTANCE_MODULE", "-shared")) if c != "-c"]
-        jobs.append((so, cmd, _fresh(so, cmd[1:])))
-    todo = [(so, cmd) for so, cmd, fresh in jobs if not fresh]
-    lock = None
-    if todo:   # one process per GPU: eight ranks meeting a new geometry at the same moment must not write the same files at once
-        import fcntl
-        lock = open(inst_dir / f".lock_{Dp}_{Dep}_{Dhp}", "w")
+        jobs.append((so, cmd))
+    # One process per GPU: eight ranks meeting a new geometry at the same moment must not write the same files at once, and none
+    # may load a module another rank is still writing -- the freshness check runs UNDER the lock, and a module is compiled under a
+    # temporary name and renamed into place (a .so that exists is a complete one).
+    import fcntl
+    with open(inst_dir / f".lock_{Dp}_{Dep}_{Dhp}", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        todo = [(so, cmd) for so, cmd, _ in jobs if not _fresh(so, cmd[1:])]     # (another rank may have built them meanwhile)
-    if todo:
-        cc = hipcc()          # raises when there is no compiler: a new geometry cannot be served on this machine
-        if verbose:
-            print(f"[qinco_amd.build] compiling {len(todo)} kernel instance(s) for ({Dp}, {Dep}, {Dhp}) [model ({D}, {De}, {Dh})]",
-                  file=sys.stderr)
+        todo = [(so, cmd) for so, cmd in jobs if not _fresh(so, cmd[1:])]
+        if todo:
+            cc = hipcc()          # raises when there is no compiler: a new geometry cannot be served on this machine
+            if verbose:
+                print(f"[qinco_amd.build] compiling {len(todo)} kernel instance(s) for ({Dp}, {Dep}, {Dhp}) [model ({D}, {De}, {Dh})]",
+                      file=sys.stderr)
 
-        def compile_one(job):
-            so, cmd = job
-            _run([cc, *cmd[1:], "-MD", "-MF", str(so.with_suffix(".d"))])
-            so.with_suffix(".cmd").write_text(" ".join(cmd[1:]))
-        try:
+            def compile_one(job):
+                so, cmd = job
+                tmp = so.with_suffix(f".tmp{os.getpid()}.so")
+                real = [cc, *[str(tmp) if c == str(so) else c for c in cmd[1:]]]
+                _run([*real, "-MD", "-MF", str(so.with_suffix(".d"))])
+                os.replace(tmp, so)
+                so.with_suffix(".cmd").write_text(" ".join(cmd[1:]))
             with cf.ThreadPoolExecutor(max_workers=len(todo)) as ex:
                 list(ex.map(compile_one, todo))
-        finally:
-            if lock is not None:
-                lock.close()
-                lock = None
-    if lock is not None:
-        lock.close()
-    for so, _, _ in jobs:                    # the encode instance first: the first entry of a shape is its production instance
+    for so, _ in jobs:                       # the encode instance first: the first entry of a shape is its production instance
         _lib.check(lib.qinco_load_instance(str(so).encode()))
     return jobs[0][0]
 

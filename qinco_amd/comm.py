@@ -38,29 +38,46 @@ def _librccl() -> C.CDLL:
 
 
 class RcclComm:
-    """ncclCommInitRank over a unique id exchanged through `id_file` (rank 0 writes it, the others wait for it)."""
+    """ncclCommInitRank over a unique id exchanged through `id_file` (rank 0 writes it, the others wait for it).  max_skew_s: how
+    much older than this rank's own start the file may be (ranks of one job start within seconds of each other)."""
 
-    def __init__(self, rank: int, world: int, id_file: str, timeout_s: float = 120.0):
+    def __init__(self, rank: int, world: int, id_file: str, timeout_s: float = 120.0, max_skew_s: float = 30.0):
         _lib.load()                      # one HIP runtime first
         self.rccl = _librccl()
         self.rank, self.world = rank, world
         uid = NcclUniqueId()
+        # The id file carries a start time next to the id: a file left behind by an EARLIER job (same path) is older than this
+        # process and is ignored by the waiting ranks -- they would otherwise hang in ncclCommInitRank on a dead id.  Rank 0
+        # replaces the file atomically and removes it once every rank has joined.
+        born = time.time()
         if rank == 0:
             self._ok(self.rccl.ncclGetUniqueId(C.byref(uid)))
-            tmp = id_file + ".tmp"
+            tmp = id_file + f".tmp{os.getpid()}"
             with open(tmp, "wb") as f:
                 f.write(bytes(uid.internal))
             os.replace(tmp, id_file)
         else:
             t0 = time.time()
-            while not os.path.exists(id_file):
+            while True:
+                try:
+                    fresh = os.path.getmtime(id_file) >= born - max_skew_s
+                    blob = open(id_file, "rb").read() if fresh else b""
+                except OSError:
+                    blob = b""
+                if len(blob) == 128:
+                    break
                 if time.time() - t0 > timeout_s:
-                    raise TimeoutError(f"no RCCL unique id at {id_file}")
+                    raise TimeoutError(f"no fresh RCCL unique id at {id_file}")
                 time.sleep(0.05)
-            C.memmove(C.byref(uid), open(id_file, "rb").read(), 128)
+            C.memmove(C.byref(uid), blob, 128)
         self.comm = C.c_void_p()
         self.rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
         self._ok(self.rccl.ncclCommInitRank(C.byref(self.comm), world, uid, rank))
+        if rank == 0:               # every rank has joined (the call is collective): the id has served
+            try:
+                os.remove(id_file)
+            except OSError:
+                pass
 
     def _ok(self, rc: int):
         if rc != 0:

@@ -77,15 +77,21 @@ extern "C" int qinco_gather_codes(const void* codes_local, int64_t n_local, int3
   const Rccl& R = rccl();
   if (!R.ok()) return fail(QINCO_ERR_UNSUPPORTED, "qinco_gather_codes: no RCCL in this process (ncclSend / ncclRecv not found; librccl.so.1 not loadable)");
   RCCL_TRY(R.group_start());
+  // (an error inside the group must still CLOSE it -- an open group on this thread would swallow every later collective of the process)
+  int grc = 0;
   if (rank != root) {
-    if (n_local > 0) RCCL_TRY(R.send(const_cast<void*>(codes_local), (size_t)n_local * rowb, kNcclUint8, root, nccl_comm, st));
+    if (n_local > 0) grc = R.send(const_cast<void*>(codes_local), (size_t)n_local * rowb, kNcclUint8, root, nccl_comm, st);
   } else {
     size_t off = 0;
-    for (int r = 0; r < world; ++r) {
+    for (int r = 0; r < world && grc == 0; ++r) {
       const size_t bytes = (size_t)counts[r] * rowb;
-      if (r != root && bytes) RCCL_TRY(R.recv(static_cast<char*>(out) + off, bytes, kNcclUint8, r, nccl_comm, st));
+      if (r != root && bytes) grc = R.recv(static_cast<char*>(out) + off, bytes, kNcclUint8, r, nccl_comm, st);
       off += bytes;
     }
+  }
+  if (grc != 0) {
+    (void)R.group_end();
+    RCCL_TRY(grc);
   }
   RCCL_TRY(R.group_end());
   if (rank == root && n_local > 0) {   // the root's own shard: a device copy into its place

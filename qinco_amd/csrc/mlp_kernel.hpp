@@ -39,8 +39,8 @@
 //             for the two-block qinco2-S.
 // 2048 SELEP  (identity projections, shared ring) the step's per-vector top-T in the epilogue, when MlpArgs::sel_T > 0 and a vector's
 //             F * A candidates sit inside one workgroup (128 % (F A) == 0): the candidates stay in z's registers, their
-//             distances meet in LDS, one wave per vector runs beam_select_kernel's selection (select.hpp wave_top_t), and only the T
-//             winners are stored -- rows straight into the next step's xhat, codes into its history.  No candidate / distance
+//             (distance, index) keys meet in LDS, every row counts the keys below its own -- its rank in beam_select_kernel's order
+//             -- and only the T winners are stored: rows straight into the next step's xhat, codes into its history.  No candidate / distance
 //             write-back (512 + 4 B per row of which the selection used 1/16), no beam_select launch.  Same distances, same
 //             selection: bit-identical codes.
 #pragma once
@@ -473,6 +473,15 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
       // ---- E': candidates in place (z <- (z + coeff*c) + xhat), distances, per-vector top-T, winners only ----------------------
       const long nv = g / a.F;
       const float* xptr = a.x + nv * D + half * 4;
+      // every row fetches its parent beam's code history now, with the epilogue operands (a winner then stores it without another
+      // round trip at the end of the workgroup's life); histories longer than 8 codes go the cooperative way below
+      constexpr int HP = 8;
+      int hv[HP];
+      const bool hist_inline = a.sel_m <= HP;
+      if (hist_inline && half == 0) {
+#pragma unroll
+        for (int jj = 0; jj < HP; ++jj) hv[jj] = jj < a.sel_m ? a.sel_hist_in[g * a.sel_M + jj] : 0;
+      }
       float s2 = 0.f, sx = 0.f, xn = 0.f;
       static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
         f32x16 o = z[ob];
@@ -491,33 +500,43 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
       sx += __shfl_xor(sx, 32);
       xn += __shfl_xor(xn, 32);
       const float dist = (xn + s2) - 2.f * sx;
-      __shared__ float sel_dv[128];
+      // Selection by counting: a candidate's rank among the vector's C = (distance, index) keys -- beam_select_kernel's order
+      // (select.hpp: sel_key, ties -> lower index) -- is the number of keys below its own: C / 2 LDS reads per lane, all rows at once,
+      // no serial chain at the end of the workgroup's life (a one-wave wave_top_t here cost 6 % of a qinco2-S encode).  Ranks are a
+      // permutation of 0 .. C-1: rank < T = winner, and the rank is its place in the next beam.
+      __shared__ unsigned long long sel_keys[128];
       __shared__ int sel_idx[128];
-      __shared__ int sel_rank[128];
-      __shared__ unsigned long long sel_surv[4 * SEL_SURV];
       auto lds_barrier = [&]() QINCO_LAMBDA {   // (raw: __syncthreads would also wait for the ring's tail DMAs)
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       };
-      const int rl = wave * 32 + j;   // row within the workgroup
-      if (half == 0) {
-        sel_dv[rl] = dist;
-        sel_rank[rl] = -1;
-      }
-      lds_barrier();
       const int C = a.A * a.F, T = a.sel_T;
+      const int rl = wave * 32 + j;          // row within the workgroup
+      const int v = rl / C, bi = rl - v * C;   // its vector within the workgroup, its flat candidate index
       const long n0 = ((long)blockIdx.x * 128) / C, nvec = a.R / C;
-      for (int v = wave_u; v < 128 / C; v += 4) {   // one wave per vector of the workgroup
-        if (n0 + v < nvec) {
-          wave_top_t(sel_dv + v * C, C, T, sel_surv + wave_u * SEL_SURV, sel_idx + v * C, lane);
-          for (int t = lane; t < T; t += 64) sel_rank[v * C + sel_idx[v * C + t]] = t;
-        }
-      }
+      const unsigned long long mine = ((unsigned long long)sel_key(dist) << 32) | (unsigned)bi;
+      if (half == 0) sel_keys[rl] = mine;
       lds_barrier();
-      const int rk = sel_rank[rl];
-      if (valid && rk >= 0) {
+      stamp(7);   // distances computed, keys published
+      int rk = 0;
+      {   // (the two lanes of a row split the keys; eight independent LDS reads in flight, not one round trip per key)
+        const unsigned long long* kv = sel_keys + v * C + half * (C / 2);
+        int i = 0;
+        for (; i + 8 <= C / 2; i += 8) {
+          unsigned long long k8[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) k8[u] = kv[i + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) rk += k8[u] < mine ? 1 : 0;
+        }
+        for (; i < C / 2; ++i) rk += kv[i] < mine ? 1 : 0;
+        if (C & 1) rk += (half == 0 && sel_keys[v * C + C - 1] < mine) ? 1 : 0;
+      }
+      rk += __shfl_xor(rk, 32);
+      const bool winner = valid && rk < T;
+      if (winner) {
         const long orow = nv * T + rk;
         float* outp = a.sel_xhat_out + orow * D + half * 4;
         static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
@@ -527,14 +546,40 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
             *reinterpret_cast<f32x4*>(outp + ob * 32 + 8 * q) = t;
           }
         });
-        if (half == 0) {   // the winner's code history: its parent beam's codes, then its own (qinco_inference.py:203-210)
-          const int* hin = a.sel_hist_in + g * a.sel_M;
-          int* hout = a.sel_hist_out + orow * a.sel_M;
-          for (int jj = 0; jj < a.sel_m; ++jj) hout[jj] = hin[jj];
-          hout[a.sel_m] = cid;
+        if (half == 0) {
+          if (hist_inline) {
+            int* hout = a.sel_hist_out + orow * a.sel_M;
+#pragma unroll
+            for (int jj = 0; jj < HP; ++jj)
+              if (jj < a.sel_m) hout[jj] = hv[jj];
+            hout[a.sel_m] = cid;
+          } else {
+            sel_idx[v * C + rk] = bi;
+          }
         }
       }
+      if (hist_inline) {
+        stamp(4);   // epilogue issued
+        if constexpr (LDSR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(5);   // stores / tail DMAs retired
+        return;
+      }
+      lds_barrier();
+      // the winners' code histories -- the parent beam's codes, then the winner's own (qinco_inference.py:203-210) -- one element
+      // per thread (a loop per winner would chain sel_m dependent round trips at the very end of the workgroup's life)
+      const int per = T * (a.sel_m + 1);
+      for (int e = threadIdx.x; e < (128 / C) * per; e += 256) {
+        const int vv = e / per, r = e - vv * per, t = r / (a.sel_m + 1), jj = r - t * (a.sel_m + 1);
+        const long nn = n0 + vv;
+        if (nn >= nvec) break;
+        const int wi = sel_idx[vv * C + t], f = wi / a.A;
+        const int val = jj < a.sel_m ? a.sel_hist_in[(nn * a.F + f) * a.sel_M + jj]
+                                     : (a.cand_ids ? a.cand_ids[nn * C + wi] : wi - f * a.A);
+        a.sel_hist_out[(nn * T + t) * a.sel_M + jj] = val;
+      }
+      stamp(4);   // epilogue issued
       if constexpr (LDSR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(5);   // stores / tail DMAs retired
       return;
     }
   }

@@ -151,7 +151,7 @@ struct qinco_handle_s {
   // through HBM.  When the shape has an un-folded instance, decode uses it with its own (complete) weight stream.
   const MlpInstance* dec_inst = nullptr;
   StreamDims dec_sd{};
-  // the encode instance with the per-vector top-T in its epilogue (VAR bit 2048, same weight stream), when the shape has one
+  // opt-in (QINCO_CREATE_EPILOGUE_SELECT): the encode instance with the per-vector top-T in its epilogue (VAR bit 2048, same weight stream)
   const MlpInstance* sel_inst = nullptr;
   std::vector<f32x4*> dec_wstream;
   // small-launch form (mlp_small_kernel.hpp): its weight stream (every step, contiguous), per-step table pointers, largest NT
@@ -896,7 +896,7 @@ struct CreateOpts {
 };
 static const int kCreateFlagMask = QINCO_CREATE_SPLIT_F16 | QINCO_CREATE_IVF_FP32 | QINCO_CREATE_TABLE_VALU | QINCO_CREATE_DECODE_FOLDED |
                                    QINCO_CREATE_TABLE_NO_COOP | QINCO_CREATE_SPLIT_NO_CALIBRATION | QINCO_CREATE_NO_PRESEL_FUSION |
-                                   QINCO_CREATE_NO_SMALL_LAUNCH | QINCO_CREATE_NO_EPILOGUE_SELECT;
+                                   QINCO_CREATE_NO_SMALL_LAUNCH | QINCO_CREATE_EPILOGUE_SELECT;
 
 static void env_opts(CreateOpts& o) {
 #ifdef QINCO_EXPERIMENT
@@ -907,7 +907,7 @@ static void env_opts(CreateOpts& o) {
   if (getenv("QINCO_TABLE_NO_COOP")) o.flags |= QINCO_CREATE_TABLE_NO_COOP;
   if (getenv("QINCO_NO_PRESEL_FUSION")) o.flags |= QINCO_CREATE_NO_PRESEL_FUSION;
   if (getenv("QINCO_NO_SMALL_LAUNCH")) o.flags |= QINCO_CREATE_NO_SMALL_LAUNCH;
-  if (getenv("QINCO_NO_EPILOGUE_SELECT")) o.flags |= QINCO_CREATE_NO_EPILOGUE_SELECT;
+  if (getenv("QINCO_EPILOGUE_SELECT")) o.flags |= QINCO_CREATE_EPILOGUE_SELECT;
   if (const char* e = getenv("QINCO_TABLE_COOP_MAX")) o.table_coop_max = atol(e);
   if (const char* e = getenv("QINCO_MLP_VARIANT")) sscanf(e, "%d,%d", &o.mlp_P, &o.mlp_var);
 #else
@@ -1055,7 +1055,7 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
       h->dec_sd = stream_dims(d.D, d.De, d.Dh, di->P, false, false, 32);
     }
   }
-  if (fn && !(create_flags & QINCO_CREATE_NO_EPILOGUE_SELECT) && !(fn->var & 2048) && d.De == d.D && want_var < 0) {
+  if (fn && (create_flags & QINCO_CREATE_EPILOGUE_SELECT) && !(fn->var & 2048) && d.De == d.D && want_var < 0) {
     const MlpInstance* si = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var | 2048);
     if (si && si->P == fn->P && si->var == (fn->var | 2048)) h->sel_inst = si;
   }

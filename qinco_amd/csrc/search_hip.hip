@@ -7,6 +7,7 @@
 
 #include "abi_util.hpp"
 #include "knn_kernel.hpp"
+#include "rerank_kernel.hpp"
 
 using namespace qinco;
 #define fail qinco::abi_fail
@@ -174,5 +175,31 @@ extern "C" int qinco_sqerr_sum(const float* a, const float* b, int64_t count, do
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(QINCO_ERR_HIP, "qinco_sqerr_sum failed: %s", hipGetErrorString(e));
+  return QINCO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// re-rank of per-query shortlists (run_search_ivf's re-rank stages, search_tasks.py:447-472, 497-507)
+// ---------------------------------------------------------------------------------------------
+extern "C" int qinco_rerank(const float* xq, const float* cand, int64_t nq, int32_t ns, int32_t D, int32_t k, const int64_t* ids_in,
+                            const int32_t* codes_in, int32_t Mc, int64_t* pos_out, float* dist_out, int64_t* ids_out, int32_t* codes_out,
+                            void* stream) {
+  if (nq < 0 || ns < 1 || D < 1 || k < 1 || k > ns) return fail(QINCO_ERR_INVALID, "qinco_rerank: need nq >= 0, 1 <= k <= ns, D >= 1");
+  if (nq == 0) return QINCO_OK;
+  if (!xq || !cand) return fail(QINCO_ERR_INVALID, "qinco_rerank: null buffer");
+  if ((ids_out && !ids_in) || (codes_out && (!codes_in || Mc < 1))) return fail(QINCO_ERR_INVALID, "qinco_rerank: an output without its input");
+  int P = 1;
+  while (P < ns) P <<= 1;
+  const size_t lds = (size_t)P * 8 + (size_t)D * 4;
+  if (lds > 160 * 1024) return fail(QINCO_ERR_UNSUPPORTED, "qinco_rerank: a shortlist of %d rows of %d features does not fit the 160 KiB of LDS", ns, D);
+  static size_t raised = 0;
+  if (lds > 64 * 1024 && lds > raised) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rerank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised = lds;
+  }
+  RerankArgs a{xq, cand, (long)nq, ns, D, k, P, reinterpret_cast<const long long*>(ids_in), codes_in, Mc,
+               reinterpret_cast<long long*>(pos_out), dist_out, reinterpret_cast<long long*>(ids_out), codes_out};
+  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)nq), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
+  HIP_TRY(hipGetLastError());
   return QINCO_OK;
 }

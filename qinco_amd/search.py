@@ -72,6 +72,79 @@ class KnnSearcher:
         return (ids, dist) if return_dist else ids
 
 
+def rerank(xq, cand, k: int, ids=None, codes=None) -> dict:
+    """One re-rank stage of run_search_ivf (search_tasks.py:447-472 / 497-507) on the GPU (qinco_rerank, csrc/rerank_kernel.hpp):
+    xq (nq, d), cand (nq, ns, d) float32 CUDA tensors; for every query the distances |x|^2 + |c|^2 - 2 x.c to its own ns candidates
+    (compute_batch_distances(..., approx=True)), sorted ascending (ties -> the earlier shortlist position), the first k kept.
+    Returns {"pos": (nq, k) positions in the shortlist, "dist": (nq, k), "ids": ids (nq, ns) gathered to (nq, k) if given,
+    "codes": codes (nq, ns, Mc) int32 gathered to (nq, k, Mc) if given}; asynchronous on the current stream."""
+    import torch
+    lib = _lib.load()
+    xq = xq.to(torch.float32).contiguous()
+    cand = cand.to(torch.float32).contiguous()
+    nq, ns, d = cand.shape
+    if xq.shape != (nq, d):
+        raise ValueError(f"xq must be ({nq}, {d}), got {tuple(xq.shape)}")
+    dev = cand.device
+    pos = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out = {"pos": pos, "dist": dist}
+    ids_in = ids_out = codes_in = codes_out = None
+    Mc = 0
+    if ids is not None:
+        ids_in = ids.to(device=dev, dtype=torch.int64).contiguous()
+        ids_out = out["ids"] = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    if codes is not None:
+        codes_in = codes.to(device=dev, dtype=torch.int32).contiguous().reshape(nq, ns, -1)
+        Mc = codes_in.shape[2]
+        codes_out = out["codes"] = torch.empty((nq, k, Mc), dtype=torch.int32, device=dev)
+    ptr = lambda t: t.data_ptr() if t is not None else None          # noqa: E731
+    _lib.check(lib.qinco_rerank(xq.data_ptr(), cand.data_ptr(), nq, ns, d, int(k), ptr(ids_in), ptr(codes_in), Mc, pos.data_ptr(),
+                                dist.data_ptr(), ptr(ids_out), ptr(codes_out), torch.cuda.current_stream(dev).cuda_stream))
+    return out
+
+
+def rerank_ivf(model: Callable, xq, I, codes_int32, *, nshort: int, mid_reranker: Optional[Callable] = None, ivf_book=None,
+               batch_size: int = 12288, topk: int = 100) -> dict:
+    """The re-rank stages of run_search_ivf (search_tasks.py:447-507) behind the IVF shortlist that faiss hands over:
+      xq (nq, d) queries, I (nq, n_short_ivf) database ids and codes_int32 (nq * n_short_ivf, M + 1) their code rows (IVF id in
+      column 0), as search_tasks.py:418-445 assembles them;
+      Part 3 (only if nshort < n_short_ivf): approximate reconstructions from the look-up decoder -- mid_reranker(codes_MB,
+        ivf_codes) -> (n, d), e.g. qinco_amd.lut.PairwiseDecoder -- plus the IVF centroid ivf_book[codes[:, 0]]
+        (model.qinco_model.steps[0].ivf_centroids.weight in the reference), distances to the query, the nshort best kept with
+        their ids and code rows (rerank);
+      Part 4: QINCo decode of the kept code rows in batches of cfg.search.batch_size = 12 288 through model(codes.T, step="decode")
+        (the small-launch form of the fused MLP: one launch per batch);
+      Part 5: distances of the decoded vectors to the query, the topk = 100 best ids.
+    Everything stays on the GPU.  Returns {"I": (nq, topk) final ids, "I_mid", "codes_mid": the stage-3 survivors (None without
+    that stage), "decoded": (nq, nshort, d), "dist": (nq, topk)}."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xq = torch.as_tensor(np.asarray(xq, dtype=F32) if not _is_torch(xq) else xq).to(dev, torch.float32)
+    I = torch.as_tensor(np.asarray(I) if not _is_torch(I) else I).to(dev, torch.int64)
+    codes = torch.as_tensor(np.asarray(codes_int32) if not _is_torch(codes_int32) else codes_int32).to(dev, torch.int32)
+    nq, n_short_ivf = I.shape
+    d, Mc = xq.shape[1], codes.shape[1]
+    I_mid = codes_mid = None
+    if nshort < n_short_ivf:
+        if mid_reranker is None or ivf_book is None:
+            raise ValueError("nshort < n_short_ivf needs the mid re-ranker and the IVF centroids (search_tasks.py:447-451)")
+        ct = codes.T
+        approx = mid_reranker(ct[1:], ct[0])
+        approx = torch.as_tensor(approx).to(dev, torch.float32) if not (_is_torch(approx) and approx.is_cuda) else approx
+        book = torch.as_tensor(np.asarray(ivf_book, dtype=F32) if not _is_torch(ivf_book) else ivf_book).to(dev, torch.float32)
+        approx = approx + book[codes[:, 0].long()]
+        r = rerank(xq, approx.reshape(nq, n_short_ivf, d), nshort, ids=I, codes=codes.reshape(nq, n_short_ivf, Mc))
+        I_mid, codes_mid = r["ids"], r["codes"]
+        I, codes = I_mid, codes_mid.reshape(nq * nshort, Mc)
+    else:
+        nshort = n_short_ivf
+    parts = [model(codes[i:i + batch_size].T, step="decode") for i in range(0, len(codes), batch_size)]
+    decoded = torch.cat([p if _is_torch(p) else torch.from_numpy(np.asarray(p)).to(dev) for p in parts]).reshape(nq, nshort, d)
+    r = rerank(xq, decoded, min(topk, nshort), ids=I)
+    return {"I": r["ids"], "dist": r["dist"], "I_mid": I_mid, "codes_mid": codes_mid, "decoded": decoded}
+
+
 def compute_recalls(I, gt) -> dict:
     """search_tasks.py:275-282: fraction of queries whose first ground-truth id is among the first `rank` results."""
     I = np.asarray(I.cpu() if _is_torch(I) else I)

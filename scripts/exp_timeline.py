@@ -20,7 +20,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 cfg = BASELINE_CONFIGS[wl]
 sd = synth_state_dict(cfg, 1236)
 import os
-eng = QincoEngine(cfg, sd, max_batch=n, split_f16=bool(int(os.environ.get("QINCO_SPLIT_F16", "0"))))
+eng = QincoEngine(cfg, sd, max_batch=n, split_f16=bool(int(os.environ.get("QINCO_SPLIT_F16", "0"))),
+                  diagnostics={"epilogue_select": True} if not os.environ.get("QINCO_NO_SELEP") else None)
 x = torch.from_numpy(synth_vectors(cfg, sd, n, seed=1)).cuda()
 lib = eng.lib
 lib.qinco_debug_timeline.restype = C.c_long
@@ -36,7 +37,8 @@ def report(label):
          "ring_prologue": float((t[:, 1] - t[:, 0]).mean()), "head_operands_ready": float((t[:, 2] - t[:, 0]).mean()),
          "ffn_blocks": float((t[:, 3] - t[:, 2]).mean()), "epilogue_issue": float((t[:, 4] - t[:, 3]).mean()),
          "retire": float((t[:, 5] - t[:, 4]).mean()),
-         "first_down_phase": float((t[:, 6] - t[:, 2]).mean()) if t[:, 6].any() else None, "wave_total": float((t[:, 5] - t[:, 0]).mean()),
+         "first_down_phase": float((t[:, 6] - t[:, 2]).mean()) if t[:, 6].any() else None,
+         "selep_keys_published": float((t[:, 7] - t[:, 3]).mean()) if t[:, 7].any() else None, "wave_total": float((t[:, 5] - t[:, 0]).mean()),
          "makespan": float(t[:, 5].max() - t[:, 0].min()), "unit": "cycles of s_memtime (100 MHz constant clock x ? -- compare ratios)"}
     # workgroup turn-around on a CU slot: sort waves of (approximately) one slot is unknown; report the distribution of start times
     starts = np.sort(t[:, 0] - t[:, 0].min())

@@ -32,12 +32,20 @@ def main():
             eng.encode(x[o:o + n], code_dtype=np.uint8 if not cfg.ivf else np.int32)
     call(0)
     torch.cuda.synchronize()
+    eng.profile_enable(True)
+    eng.profile_read()
     t0 = time.perf_counter()
     for i in range(reps):
         call(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    pr = eng.profile_read()
     print(f"{wl} {mode} rows={n}: {reps * n / dt:.0f} vectors/s, {dt / reps * 1e6:.1f} us per call")
+    # what the library says the matrix pipe executed (qinco_profile_read2) -- the figure the SQ_INSTS_VALU_MFMA_MOPS_F32 pass checks
+    import json
+    print("LIBRARY " + json.dumps({"workload": wl, "mode": mode, "rows": n, "calls_counted": reps, "mlp_launches": pr["mlp_launches"],
+                                  "executed_flops_per_call": pr["mlp_flops_executed"] / reps, "algorithmic_flops_per_call": pr["mlp_flops"] / reps,
+                                  "mlp_ms_per_call": pr["mlp_ms"] / reps}))
 
 
 if __name__ == "__main__":

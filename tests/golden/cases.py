@@ -55,8 +55,11 @@ CASES = {
     "trained_qinco1": Case(None, 2102, 128, ckpt="trained_qinco1.pt", data="small"),
     "trained_tiny_proj": Case(None, 2104, 192, ckpt="trained_tiny_proj.pt", data="small"),    # De != D: trained projections
     "trained_ivf_qinco2S": Case(None, 2103, 192, ckpt="trained_ivf_qinco2S.pt", data="u8"),  # frozen coarse codebook of 2048 in front
+    # the headline kernel's own shape (de = dh = 384, L = 16), trained by the reference: beam search and the greedy override
+    "trained_qinco2L": Case(None, 2105, 128, ckpt="trained_qinco2L.pt", data="u8"),
+    "trained_qinco2L_b1": Case(None, 2105, 128, ckpt="trained_qinco2L.pt", data="u8"),
 }
-SEARCH_OVERRIDE = {"trained_qinco2S_b1": dict(B=1)}      # CLI-style override of the stored search width (utils.py:166-172)
+SEARCH_OVERRIDE = {"trained_qinco2S_b1": dict(B=1), "trained_qinco2L_b1": dict(B=1)}      # CLI-style override of the stored search width (utils.py:166-172)
 
 
 def case_model(name: str):

@@ -206,8 +206,78 @@ def run_search_case() -> dict:
             "dist_sorted": dsorted.astype(np.float32), "recalls": np.asarray(recalls, np.float64)}
 
 
+def run_rerank_case() -> dict:
+    """The re-rank stages of run_search_ivf (qinco/search/search_tasks.py:447-507; the module itself needs faiss to import), driven
+    line by line with the reference's own pieces: compute_batch_distances(approx=True) (qinco/utils.py:349-383), torch.argsort /
+    take_along_dim, and the reference's inference wrapper for the QINCo decode in batches of cfg.search.batch_size.  The shortlist
+    that faiss's index.search_and_return_codes would hand over is made here (each query's true neighbours among its own
+    reconstructions + random rows), and so is the mid re-ranker's output: PairwiseDecoderIVF cannot be imported (torcheval), its
+    reconstructions enter as a given (n, d) array built from a look-up table with this repo's own formula -- that look-up stays
+    "parity unpinned"; everything downstream of it is the reference's arithmetic."""
+    from qinco.utils import compute_batch_distances
+    cfg, sd = case_model("tiny_ivf_beam")
+    model, wrapper = build_reference(cfg, sd)
+    M, d = cfg.M, cfg.D
+    N, nq, n_short_ivf, nshort, bs = 3000, 24, 160, 40, 512
+    rs = np.random.RandomState(91)
+    with torch.no_grad():
+        base = model(torch.from_numpy(synth_codes(cfg, N, seed=92)), step="decode").numpy()
+        db = (base + 0.3 * float(sd["data_std"]) * rs.randn(N, d)).astype(np.float32)
+        codes_db = wrapper(torch.from_numpy(db), step="encode").numpy().T.astype(np.int32)      # (N, M + 1): IVF id first
+        xhat_db = wrapper(torch.from_numpy(codes_db.T.astype(np.int64)), step="decode").numpy()
+    xq = (db[rs.choice(N, nq, replace=False)] + 1.0 * float(sd["data_std"]) * rs.randn(nq, d)).astype(np.float32)
+    dq = ((xq[:, None, :].astype(np.float64) - xhat_db[None].astype(np.float64)) ** 2).sum(-1)
+    near = np.argsort(dq, axis=1, kind="stable")[:, :n_short_ivf // 2]
+    I = np.stack([rs.permutation(np.concatenate([near[q], rs.choice(np.setdiff1d(np.arange(N), near[q]), n_short_ivf - near.shape[1],
+                                                                   replace=False)])) for q in range(nq)]).astype(np.int64)
+    codes_int32 = codes_db[I.reshape(-1)]                                                     # (nq * n_short_ivf, M + 1)
+    # the mid re-ranker's stand-in: a pairwise look-up table T[j][c_a K + c_b] over (step 1, step 2), ..., rough reconstructions
+    K = cfg.K
+    pairs = [(0, 1), (1, 2)] if M >= 3 else [(0, 1)]
+    cb = [np.asarray(sd[f"steps.{m + 1}.codebook.weight"], np.float32) for m in range(M)]
+    tables = np.stack([(cb[a][:, None, :] + 0.5 * cb[b][None, :, :]).reshape(K * K, d) for a, b in pairs]).astype(np.float32)
+    comb = np.array([[a for a, _ in pairs], [b for _, b in pairs]], np.int64)
+    qc = codes_int32[:, 1:].astype(np.int64)
+    mid = np.zeros((len(qc), d), np.float32)
+    for j in range(len(pairs)):
+        mid = mid + tables[j][qc[:, comb[0, j]] * K + qc[:, comb[1, j]]]
+    ivf_book_t = model.steps[0].ivf_centroids.weight.detach()
+    # (the tables are a function of the model's codebooks: the test rebuilds them with the same two lines instead of storing 16 MB)
+    out = {"xq": xq, "I": I, "codes_int32": codes_int32, "pair_combine": comb, "mid_shortlist": mid,
+           "ivf_book": ivf_book_t.numpy(), "nshort": np.int64(nshort), "batch_size": np.int64(bs)}
+    with torch.no_grad():
+        xq_distances = torch.from_numpy(xq)
+        I_t, codes_t = torch.from_numpy(I), torch.from_numpy(codes_int32)
+        # ---- Part 3 (search_tasks.py:447-472)
+        shortlist = torch.from_numpy(mid).clone()
+        shortlist += ivf_book_t[codes_t[:, 0].long()]
+        shortlist = shortlist.reshape(nq, n_short_ivf, d)
+        D_refined = compute_batch_distances(xq_distances.reshape(nq, 1, d), shortlist, approx=True).reshape(nq, n_short_ivf)
+        idx = torch.argsort(D_refined, axis=1, stable=True)
+        codes_refined = torch.take_along_dim(codes_t.reshape(nq, n_short_ivf, M + 1), idx[:, :nshort, None], dim=1)
+        I_mid = torch.take_along_dim(I_t, idx[:, :nshort], dim=1)
+        out["mid_dist_sorted"] = torch.sort(D_refined, dim=1).values.numpy()
+        out["I_mid"], out["codes_mid"] = I_mid.numpy(), codes_refined.numpy()
+        codes2 = codes_refined.reshape(nq * nshort, M + 1)
+        # ---- Part 4 (:475-486): QINCo decode in batches of cfg.search.batch_size
+        parts = [wrapper(codes2[i:i + bs].T.long(), step="decode") for i in range(0, len(codes2), bs)]
+        shortlist_t = torch.concatenate(parts).reshape(nq, nshort, d)
+        # ---- Part 5 (:497-507)
+        D2 = compute_batch_distances(xq_distances.reshape(nq, 1, d), shortlist_t, approx=True).reshape(nq, nshort)
+        idx2 = torch.argsort(D2, axis=1, stable=True)
+        out["final_dist_sorted"] = torch.sort(D2, dim=1).values.numpy()
+        out["I_refined"] = torch.take_along_dim(I_mid, idx2[:, :100], dim=1).numpy()
+        out["decoded_shortlist"] = shortlist_t.numpy()
+    g1 = np.diff(out["mid_dist_sorted"], axis=1) / np.maximum(np.abs(out["mid_dist_sorted"][:, 1:]), 1e-12)
+    g2 = np.diff(out["final_dist_sorted"], axis=1) / np.maximum(np.abs(out["final_dist_sorted"][:, 1:]), 1e-12)
+    print(f"rerank_ivf               nq={nq} shortlist {n_short_ivf} -> {nshort} -> {out['I_refined'].shape[1]}; min rel gaps {g1.min():.2e} {g2.min():.2e}")
+    return out
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    if not only or "rerank_ivf" in only:
+        np.savez_compressed(HERE / "rerank_ivf.npz", **run_rerank_case())
     if not only or "search_small_db" in only:
         np.savez_compressed(HERE / "search_small_db.npz", **run_search_case())
     for name in CASES:

@@ -88,6 +88,10 @@ SPECS = {
     # IVF-QINCo2-S-shaped: a frozen coarse codebook of 2048 k-means centroids in front (qinco_tasks.py:277-300), M = 4 steps after it
     "trained_ivf_qinco2S": dict(kind="u8", D=128, M=4, K=256, L=2, de=128, dh=256, A=16, B=8, qinco1_mode=False, ivf_K=2048,
                                 steps=1000, batch=256, lr=8e-4, opt="adamw", clip=0.1, seed=2103),
+    # the HEADLINE kernel's own shape (qinco2-L: de = dh = 384, sixteen residual blocks) with one QINCo step behind step 0: sixteen
+    # blocks deep is where trained activation growth meets the folded head's fp32 association and the split form's scalings
+    "trained_qinco2L": dict(kind="u8", D=128, M=2, K=256, L=16, de=384, dh=384, A=16, B=8, qinco1_mode=False,
+                            steps=1200, batch=96, lr=8e-4, opt="adamw", clip=0.1, seed=2105),
 }
 
 

@@ -84,6 +84,7 @@ SPLIT_CASES = ["tiny_proj_dh128", "C2_qinco2L_8x8_b8", "C2_qinco2L_8x8_b1", "C3_
                # round 3: checkpoints trained by the reference, and the datasets' real normalisation magnitudes / byte inputs
                # (the split form picks its power-of-two operand scalings from the weights: this is where that could break)
                "trained_qinco2S", "trained_qinco2S_b1", "trained_qinco1", "trained_ivf_qinco2S", "trained_tiny_proj",
+               "trained_qinco2L", "trained_qinco2L_b1",     # round 4: the headline kernel's own shape, trained by the reference
                "norm_bigann_u8", "norm_ssnpp_u8", "norm_contriever"]
 
 
@@ -463,10 +464,10 @@ def test_small_launch_form_is_bit_identical_to_the_128_row_kernels(shape):
 @pytest.mark.parametrize("shape,A,B", [("qinco2-S", 16, 8), ("qinco2-S", 16, 4), ("qinco2-S", 16, 2), ("qinco2-S", 8, 16), ("qinco2-S", 32, 4),
                                        ("tiny_id", 8, 4), ("tiny_id", 8, 16), ("tiny_id", 4, 8), ("tiny_id", 16, 1)])
 def test_epilogue_selection_is_bit_identical_to_beam_select(shape, A, B):
-    """Identity-projection models whose F * A candidates per vector fit a 128-row workgroup take the step's top-B inside the
-    fused-MLP kernel's epilogue (csrc/mlp_kernel.hpp SELEP): no candidate / distance write-back, no beam_select launch.  Same
-    distances, same selection code (select.hpp wave_top_t): codes and tracked reconstructions must equal the two-kernel form bit for
-    bit -- at sizes where the last workgroup is partly empty, with heavy ties (duplicated vectors), and with the beam still
+    """Opt-in (epilogue_select; measured slower than the write-back it saves): identity-projection models whose F * A
+    candidates per vector fit a 128-row workgroup take the step's top-B inside the fused-MLP kernel's epilogue (csrc/mlp_kernel.hpp
+    SELEP): no candidate / distance write-back, no beam_select launch.  Same distances, the same (distance, index) order as
+    beam_select_kernel: codes and tracked reconstructions must equal the two-kernel form bit for bit -- at sizes where the last workgroup is partly empty, with heavy ties (duplicated vectors), and with the beam still
     growing in the first steps (F < B)."""
     import torch
     from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
@@ -476,8 +477,8 @@ def test_epilogue_selection_is_bit_identical_to_beam_select(shape, A, B):
     x = synth_vectors(cfg, sd, 20000, seed=78)
     x[100:200] = x[0:100]            # duplicated rows: identical candidate distances
     xd = torch.from_numpy(x).cuda()
-    fused = QincoEngine(cfg, sd, max_batch=20000)
-    plain = QincoEngine(cfg, sd, max_batch=20000, diagnostics={"no_epilogue_select": True})
+    fused = QincoEngine(cfg, sd, max_batch=20000, diagnostics={"epilogue_select": True})
+    plain = QincoEngine(cfg, sd, max_batch=20000)
     for n in (20000, 4097, 2049):      # (large enough for the 128-row kernels: below, the small-launch form serves the step)
         cf, hf = fused.encode(xd[:n], return_xhat=True)
         cp, hp = plain.encode(xd[:n], return_xhat=True)
@@ -841,7 +842,7 @@ def test_from_checkpoint_runs_encode_database_on_the_gpu(tmp_path):
 
 
 @pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_f16"])
-@pytest.mark.parametrize("name", ["trained_qinco2S", "trained_qinco1", "trained_ivf_qinco2S", "trained_tiny_proj"])
+@pytest.mark.parametrize("name", ["trained_qinco2S", "trained_qinco1", "trained_ivf_qinco2S", "trained_tiny_proj", "trained_qinco2L"])
 def test_reference_trained_checkpoint_through_from_checkpoint(name, split):
     """A checkpoint the imported reference TRAINED (tests/golden/make_trained.py) and wrote with its own save_model, loaded
     through the product's checkpoint reader and run behind the reference-shaped model object -- uint8 rows for the
@@ -852,7 +853,7 @@ def test_reference_trained_checkpoint_through_from_checkpoint(name, split):
     g = load_golden(name)
     model = QINCoHIP.from_checkpoint(str(GOLDEN / CASES[name].ckpt), max_batch=100, split_f16=split)
     assert model.built and model.engine.split_f16 == split
-    if name in ("trained_qinco2S", "trained_ivf_qinco2S"):
+    if name in ("trained_qinco2S", "trained_ivf_qinco2S", "trained_qinco2L"):
         assert g["x"].dtype == np.uint8
     codes = np.ascontiguousarray(model(g["x"], step="encode").T)
     want = ref_codes(g)

@@ -198,3 +198,50 @@ def test_search_small_db_pipeline_and_compute_mse_on_gpu():
     a = torch.randn(100003, device="cuda")
     b = torch.randn(100003, device="cuda")
     assert np.isclose(sqerr_sum(a, b), float(((a.double() - b.double()) ** 2).sum()), rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_rerank_ivf_matches_the_reference_stages():
+    """run_search_ivf's re-rank stages (search_tasks.py:447-507) as qinco_amd.search.rerank_ivf over the look-up decoder, the
+    re-rank kernel (csrc/rerank_kernel.hpp) and QINCoHIP's decode in batches, against a fixture made by driving those lines with
+    the reference's own compute_batch_distances, argsort / take_along_dim and inference wrapper (tests/golden/make_golden.py
+    run_rerank_case).  The look-up decoder's own arithmetic is "parity unpinned" (PairwiseDecoderIVF needs torcheval to import): its
+    output is checked against this repo's formula only (mid_shortlist); everything downstream is the reference's.
+    A kept id may differ from the reference's only where the reference's own sorted distances are within rounding of each other."""
+    import torch
+    from conftest import golden_model, load_golden
+    from qinco_amd.lut import PairwiseDecoder
+    from qinco_amd.model import QINCoHIP
+    from qinco_amd.search import rerank_ivf
+    g = load_golden("rerank_ivf")
+    cfg, sd = golden_model("tiny_ivf_beam")
+    K, d, M = cfg.K, cfg.D, cfg.M
+    comb = g["pair_combine"]
+    cb = [np.asarray(sd[f"steps.{m + 1}.codebook.weight"], np.float32) for m in range(M)]
+    tables = np.stack([(cb[a][:, None, :] + 0.5 * cb[b][None, :, :]).reshape(K * K, d) for a, b in comb.T]).astype(np.float32)
+    dec = PairwiseDecoder(tables, comb, K_base=K)
+    mid = dec(g["codes_int32"][:, 1:].T)
+    assert np.abs(np.asarray(mid) - g["mid_shortlist"]).max() <= 1e-5 * np.abs(g["mid_shortlist"]).max()
+    model = QINCoHIP(cfg, sd, max_batch=1024)
+    nshort, bs = int(g["nshort"]), int(g["batch_size"])
+    out = rerank_ivf(model, g["xq"], g["I"], g["codes_int32"], nshort=nshort, mid_reranker=lambda c, i: dec(c.cpu().numpy()),
+                     ivf_book=g["ivf_book"], batch_size=bs)
+    torch.cuda.synchronize()
+
+    def same_up_to_ties(got, want, dist_sorted, label):
+        got, want = np.asarray(got.cpu()), np.asarray(want)
+        assert got.shape == want.shape, (label, got.shape, want.shape)
+        gaps = np.diff(dist_sorted, axis=1) / np.maximum(np.abs(dist_sorted[:, 1:]), 1e-12)
+        for q, t in zip(*np.nonzero(got != want)):
+            near = gaps[q, max(t - 1, 0): t + 1]
+            assert near.size and near.min() < 1e-5, f"{label}: query {q} rank {t}: {got[q, t]} != {want[q, t]} without a tie"
+        return int((got != want).any(axis=1).sum())
+    n_mid = same_up_to_ties(out["I_mid"], g["I_mid"], g["mid_dist_sorted"], "stage 3")
+    if n_mid == 0:   # (the later stages work on the same survivors as the reference's only then)
+        assert np.array_equal(np.asarray(out["codes_mid"].cpu()), g["codes_mid"])
+        ref_dec = g["decoded_shortlist"]
+        assert np.abs(np.asarray(out["decoded"].cpu()) - ref_dec).max() <= 1e-5 * np.abs(ref_dec).max()
+        same_up_to_ties(out["I"], g["I_refined"], g["final_dist_sorted"], "stage 5")
+    print(f"rerank_ivf: {n_mid} queries with a stage-3 tie swap")
+    dec.close()
+    model.engine.close()

@@ -401,7 +401,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4"])
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4", "S", "IVF_S"],
+                    help="C2 = the driver's configuration (BASELINE.json configs[1]); S / IVF_S: the reference's billion-scale family, e.g. "
+                         "--scaling strong --db 80000000 --workload S as the stand-in for 10 M vectors per GPU of the 1 B-vector job")
     ap.add_argument("--batch", type=int, default=16384, help="vectors per step per GPU")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: per-GPU work fixed (K batches per rank); strong: one database split over the ranks")
@@ -522,14 +524,16 @@ def main():
         device_sync()
 
     for xb in warm:
-        eng.encode(xb, code_dtype=np.uint8)
+        eng.encode(xb, code_dtype=np.int32 if cfg.ivf else np.uint8)
     barrier()
     eng.profile_enable(True)
     eng.profile_read()
     barrier()
     t0 = time.perf_counter()
-    codes_steps = [eng.encode(xb, code_dtype=np.uint8) for xb in batches]
-    mine = torch.cat(codes_steps) if codes_steps else torch.empty((0, cfg.M_total), dtype=torch.uint8, device=dev)
+    wire_np = np.int32 if cfg.ivf else np.uint8          # (an IVF id does not fit a byte)
+    wire_t = torch.int32 if cfg.ivf else torch.uint8
+    codes_steps = [eng.encode(xb, code_dtype=wire_np) for xb in batches]
+    mine = torch.cat(codes_steps) if codes_steps else torch.empty((0, cfg.M_total), dtype=wire_t, device=dev)
     t_enc = t_gather = 0.0
     gather_how = None
     if world > 1:  # the end-of-job gather of the uint8 codes: one collective, shards padded to the longest
@@ -537,7 +541,7 @@ def main():
         t_enc = time.perf_counter() - t0
         longest = max(shard_bounds(db_size, world, r)[1] - shard_bounds(db_size, world, r)[0] for r in range(world)) if strong \
             else K * args.batch
-        pad = torch.zeros((longest, cfg.M_total), dtype=torch.uint8, device=dev)
+        pad = torch.zeros((longest, cfg.M_total), dtype=wire_t, device=dev)
         pad[: len(mine)] = mine
         try:
             hook = os.environ.get("QINCO_BENCH_FORCE_GATHER_ERROR")   # test hook (tests/test_multi_gpu.py): the fail-soft paths
@@ -623,10 +627,10 @@ def main():
                 "per_rank_encode_vectors_per_s": [t[2] / t[0] if t[0] > 0 else 0.0 for t in per_rank],
                 "per_rank_encode_s": [t[0] for t in per_rank],
                 "per_rank_gather_s": [t[1] for t in per_rank],
-                "gather_bytes_per_rank": int(longest * cfg.M_total),
+                "gather_bytes_per_rank": int(longest * cfg.M_total * (4 if cfg.ivf else 1)),
                 "note": "gather time of a rank includes waiting for the slowest rank's encode",
             }
-        if world == 1 and not args.no_extras and K > 0 and not strong:
+        if world == 1 and not args.no_extras and K > 0 and not strong and not cfg.ivf:
             extras(torch, dev, args, cfg, sd, eng, out, mine, batches, warm, value, sqerr_sum, QincoEngine)
         if world == 1 and not args.no_legs and not args.split_f16:
             out["parity"] = parity_counts(torch, dev)

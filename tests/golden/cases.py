@@ -58,6 +58,7 @@ CASES = {
     # the headline kernel's own shape (de = dh = 384, L = 16), trained by the reference: beam search and the greedy override
     "trained_qinco2L": Case(None, 2105, 128, ckpt="trained_qinco2L.pt", data="u8"),
     "trained_qinco2L_b1": Case(None, 2105, 128, ckpt="trained_qinco2L.pt", data="u8"),
+    "trained_qinco2L_d768": Case(None, 2106, 64, ckpt="trained_qinco2L_d768.pt", data="small"),   # ... on 768-d data (C4's kernel instance)
 }
 SEARCH_OVERRIDE = {"trained_qinco2S_b1": dict(B=1), "trained_qinco2L_b1": dict(B=1)}      # CLI-style override of the stored search width (utils.py:166-172)
 

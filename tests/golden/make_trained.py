@@ -92,6 +92,9 @@ SPECS = {
     # blocks deep is where trained activation growth meets the folded head's fp32 association and the split form's scalings
     "trained_qinco2L": dict(kind="u8", D=128, M=2, K=256, L=16, de=384, dh=384, A=16, B=8, qinco1_mode=False,
                             steps=1200, batch=96, lr=8e-4, opt="adamw", clip=0.1, seed=2105),
+    # ... and on 768-d data (contriever-like small-magnitude floats): the same blocks between trained in_proj / out_proj of 768 x 384
+    "trained_qinco2L_d768": dict(kind="small", D=768, M=2, K=256, L=16, de=384, dh=384, A=16, B=8, qinco1_mode=False,
+                                 steps=600, batch=64, lr=8e-4, opt="adamw", clip=0.1, seed=2106),
 }
 
 

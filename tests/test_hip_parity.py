@@ -84,7 +84,7 @@ SPLIT_CASES = ["tiny_proj_dh128", "C2_qinco2L_8x8_b8", "C2_qinco2L_8x8_b1", "C3_
                # round 3: checkpoints trained by the reference, and the datasets' real normalisation magnitudes / byte inputs
                # (the split form picks its power-of-two operand scalings from the weights: this is where that could break)
                "trained_qinco2S", "trained_qinco2S_b1", "trained_qinco1", "trained_ivf_qinco2S", "trained_tiny_proj",
-               "trained_qinco2L", "trained_qinco2L_b1",     # round 4: the headline kernel's own shape, trained by the reference
+               "trained_qinco2L", "trained_qinco2L_b1", "trained_qinco2L_d768",     # round 4: the headline kernel's own shape, trained by the reference
                "norm_bigann_u8", "norm_ssnpp_u8", "norm_contriever"]
 
 
@@ -842,7 +842,7 @@ def test_from_checkpoint_runs_encode_database_on_the_gpu(tmp_path):
 
 
 @pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_f16"])
-@pytest.mark.parametrize("name", ["trained_qinco2S", "trained_qinco1", "trained_ivf_qinco2S", "trained_tiny_proj", "trained_qinco2L"])
+@pytest.mark.parametrize("name", ["trained_qinco2S", "trained_qinco1", "trained_ivf_qinco2S", "trained_tiny_proj", "trained_qinco2L", "trained_qinco2L_d768"])
 def test_reference_trained_checkpoint_through_from_checkpoint(name, split):
     """A checkpoint the imported reference TRAINED (tests/golden/make_trained.py) and wrote with its own save_model, loaded
     through the product's checkpoint reader and run behind the reference-shaped model object -- uint8 rows for the

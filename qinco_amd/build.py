@@ -169,7 +169,7 @@ def ensure_instance(D: int, De: int, Dh: int, verbose: bool = False) -> Path | N
         inst_dir.mkdir(parents=True, exist_ok=True)
     # the encode instance, and -- for the two-workgroups-per-CU forms -- the un-folded twin decode runs on (DESIGN.md 3.1:
     # faster there, slower on the wide shapes); compiled side by side
-    variants = [var] + ([var & ~(16 | 32)] if (var & 16) and (var & 256) else [])   # (the twin pays on the OCC2 shapes only)
+    variants = [var] + ([var & ~(16 | 32 | 4096)] if (var & 16) and (var & 256) else [])   # (the twin pays on the OCC2 shapes only)
     jobs = []
     for v in variants:
         so = inst_dir / f"inst_{Dp}_{Dep}_{Dhp}_{P}_{v}.so"

@@ -37,6 +37,17 @@
 //             W_up[0] z = P[cid] + Q[group] with P = W_up[0] T (table) and Q = W_up[0] U (same xproj launch), so the
 //             kernel starts with y = relu(P[cid] + Q[group]) and the first down-projection: -2.9 % more at C2, -20 %
 //             for the two-block qinco2-S.
+// 4096 KHEAD  (OCC2 + FOLD2, round 4) the head's per-group rows are added ON THE MATRIX PIPE and the first down-projection runs
+//             K-outer, so that the gathers of the head stream under its MFMAs:
+//               z = T[cid] + U[g],  y = relu(P[cid] + Q[g]):  the per-codeword rows are gathered into registers as before, the
+//               per-group rows -- the same bytes for every row of a group -- arrive as ONE MFMA per 32-feature block with a one-hot B
+//               operand:  acc[f][row] += sum_k U[g0 + k][f] * [group(row) == g0 + k], k = 0, 1  (A: lane (f, k) holds U[g0 + k][f], one
+//               coalesced dword instead of four 16-byte gathers;  fmaf(U, 1, T) rounds like T + U and adding 0 * U' is exact: same bits).
+//               The first down-projection takes its fragments in (input block, q, output block) order with NEB accumulators, so
+//               only ONE y block has to exist at a time: y block ib + 2 is gathered while block ib is on the matrix pipe.  Per
+//               output element the products are added in the order of the ob-outer form: same bits.
+//             Before: under OCC2's 128-VGPR budget hipcc drained the head's 96 gathers in 12 batches by vmcnt(0): 68 k of a
+//             short-MLP tile's 228 k cycles (profiles/r03_timeline.jsonl) with nothing on the matrix pipe.
 // 2048 SELEP  (identity projections, shared ring) the step's per-vector top-T in the epilogue, when MlpArgs::sel_T > 0 and a vector's
 //             F * A candidates sit inside one workgroup (128 % (F A) == 0): the candidates stay in z's registers, their
 //             (distance, index) keys meet in LDS, every row counts the keys below its own -- its rank in beam_select_kernel's order
@@ -105,6 +116,32 @@ QINCO_INL void pin_v(f32x16& v) { asm volatile("" : "+v"(v)); }
 QINCO_INL void pin4_v(f32x4& v) { asm volatile("" : "+v"(v)); }
 QINCO_INL void pin_a(f32x16& v) { asm volatile("" : "+a"(v)); }
 
+// A 32-feature block of a table row requested by loads hipcc does not see as loads (KHEAD).  hipcc's wait-count pass treats every
+// LDS-DMA of the weight ring as a "flat" access that may complete out of order, so any wait IT generates for a global load while
+// a ring DMA is in flight is vmcnt(0): the whole ring and every other gather drained (that is what made the head's 12 batches 12
+// exposed round trips).  These loads are waited for by hand (wait_block: a counted vmcnt that names the registers, so no use can
+// move above it); the 16 registers are assembled from the four quads afterwards (the coalescer makes them one tuple).
+struct AsmBlock {
+  f32x4 q[4];
+};
+template <int OFF>
+QINCO_INL void asm_load_block(AsmBlock& b, const float* p) {   // bytes OFF + {0, 32, 64, 96} from p (p includes the half * 4 lane offset)
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(b.q[0]) : "v"(p), "n"(OFF) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(b.q[1]) : "v"(p), "n"(OFF + 32) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(b.q[2]) : "v"(p), "n"(OFF + 64) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(b.q[3]) : "v"(p), "n"(OFF + 96) : "memory");
+}
+template <int N>
+QINCO_INL f32x16 wait_block(AsmBlock& b) {   // "at most N vector-memory operations younger than this block's loads": then they have landed
+  asm volatile("s_waitcnt vmcnt(%4)" : "+a"(b.q[0]), "+a"(b.q[1]), "+a"(b.q[2]), "+a"(b.q[3]) : "n"(N) : "memory");
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * q + e] = b.q[q][e];
+  return v;
+}
+
 template <int D, int DE, int DH, int P, int VAR>
 __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a) {
   constexpr bool FOLD = (VAR & 16) != 0;
@@ -120,7 +157,9 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   constexpr bool SHR = (VAR & 64) != 0;
   constexpr bool G8 = (VAR & 1024) != 0;   // shared ring with a barrier / refill every 8 fragments instead of every 4 (A/B variant)
   constexpr bool SELEP = (VAR & 2048) != 0;
-  static_assert((VAR & ~(4 | 8 | 16 | 32 | 64 | 256 | 1024 | 2048)) == 0, "unknown VAR bits");
+  constexpr bool KHEAD = (VAR & 4096) != 0;
+  static_assert((VAR & ~(4 | 8 | 16 | 32 | 64 | 256 | 1024 | 2048 | 4096)) == 0, "unknown VAR bits");
+  static_assert(!KHEAD || (OCC2 && FOLD2 && SHR && !G8), "KHEAD is a form of the two-workgroups-per-CU folded kernel");
   static_assert(!SELEP || (SHR && D == DE), "SELEP: every wave reaches the epilogue's barriers, candidates live in z's registers");
   static_assert(!G8 || (SHR && P % 24 == 0 && P / 4 >= 7), "G8 is a form of the shared ring");
   static_assert(!OCC2 || (VAR & 8), "OCC2 is a form of the pinned plan");
@@ -142,8 +181,22 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
     if (a.timeline && lane == 0) a.timeline[tile * 8 + i] = __builtin_readcyclecounter();
   };
   stamp(0);
+  if (a.timeline && lane == 0 && !SELEP) {   // where the tile ran: XCC id << 32 | HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SE/SH [15:12])
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.timeline[tile * 8 + 7] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+  }
 #else
   auto stamp = [](int) QINCO_LAMBDA {};
+#endif
+#if defined(QINCO_EXPERIMENT) && defined(QINCO_STAGGER_EXP)
+  // experiment builds: the second residents of the CUs in the launch's first round (workgroups 256 .. 511 share a CU with 0 .. 255,
+  // scripts/ubench/residency.hip) start QINCO_STAGGER_EXP x 8128 cycles late
+  if constexpr (OCC2) {
+    if (blockIdx.x >= 256 && blockIdx.x < 512)
+      for (int i = 0; i < QINCO_STAGGER_EXP; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 #endif
   const long g = row / a.A;
   const int cid = a.cand_ids ? a.cand_ids[row] : (int)(row - g * a.A);
@@ -208,7 +261,10 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
     for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
   }
   stamp(1);   // ring prologue done (first fragments landed, first barrier passed)
-  auto take = [&]<int T>() QINCO_LAMBDA -> f32x4 {
+  // EX: vector-memory loads OTHER than ring DMAs that this wave has issued since the DMA this wait is for and that may still be in
+  // flight (KHEAD's head and block gathers): memory operations return in order, so the count is raised by exactly their number --
+  // with EX = 0 the wait would also drain every gather issued in the last nine groups
+  auto take = [&]<int T, int EX = 0>() QINCO_LAMBDA -> f32x4 {
     if constexpr (SHR && G8) {
       // Groups of 8.  Before fragment T = 8g every wave has issued 2g + P/4 - 2 DMAs; "<= P/4 - 5 outstanding" = its first
       // 2g + 3 landed, so past the barrier fragments <= 8g + 11 are in LDS: covers the reads (<= 8g + 9) of this group.  The
@@ -227,7 +283,7 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
       // landed, so past the barrier fragments <= 4g + 7 are in LDS: covers the reads (<= 4g + 5) of this group.
       // The refill overwrites fragments 4g - 4 .. 4g - 1, which every wave consumed before this barrier.
       if constexpr ((T & 3) == 0) {
-        wait_vm.template operator()<P / 4 - 3>();
+        wait_vm.template operator()<P / 4 - 3 + EX>();
         __builtin_amdgcn_s_barrier();
         dma.template operator()<T + P - 4>();
       }
@@ -252,8 +308,8 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   // One fragment: acc += W[ob, 8 features (4q..4q+3 of each half) of block ib] . b  (4 dependent MFMAs), then `extra`
   // (a slice of a chain epilogue that the following MFMAs do not depend on).
   auto noop = []() QINCO_LAMBDA {};
-  auto fragmm = [&]<int T, int q>(f32x16& acc, const f32x16& b, auto&& extra) QINCO_LAMBDA {
-    f32x4 w = take.template operator()<T>();
+  auto fragmm = [&]<int T, int q, int EX = 0>(f32x16& acc, const f32x16& b, auto&& extra) QINCO_LAMBDA {
+    f32x4 w = take.template operator()<T, EX>();
     // Shared ring: the barrier in front of fragment T + 1 (T = 3 mod 4) licenses the refill of the slots of fragments <= T, so
     // this wave's LDS reads of those fragments must have COMPLETED when it arrives there.  Program order alone does not give
     // that -- hipcc moves MFMAs, and with them the s_waitcnt lgkmcnt that completes a ds_read, across s_barrier (found on the
@@ -269,7 +325,40 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   f32x16 z[NEB];
   f32x16 y[NYB];
 
-  if constexpr (FOLD) {
+  // KHEAD: state that lives from the head into the first down-projection
+  constexpr int LA = 2;   // y blocks in flight ahead of the matrix pipe
+  // Gathers in flight at the ring wait of group G of the first down-projection (see take): the DMA that wait is for was issued at
+  // group G + 2 - P / 4 (in the ring prologue for G <= P / 4 - 3).  Issued since then: the head's burst (NEB + NHB dwords, LA + NEB blocks of 4
+  // loads; only while G <= 9) and the 4 loads of y block ib + LA, requested in front of group 4 NEB ib / 4 ... = block ib's first group
+  // (NEB groups per block), for every ib < NHB - LA with  first <= G <= first + P / 4 - 3.
+  constexpr auto khead_hosted = [](int G) constexpr {
+    int n = G <= P / 4 - 3 ? NEB + NHB + 4 * (LA + NEB) : 0;
+    for (int ib = 0; ib + LA < NHB; ++ib)
+      if (NEB * ib <= G && G <= NEB * ib + P / 4 - 3) n += 4;
+    return n;
+  };
+  [[maybe_unused]] AsmBlock yb[KHEAD ? LA : 1];
+  [[maybe_unused]] float ua[NEB], qa[NHB];   // (dead registers outside KHEAD)
+  [[maybe_unused]] long gbase = 0;
+  [[maybe_unused]] int dg = 0, dg_last = 0;
+  [[maybe_unused]] const float* pptr = nullptr;
+  if constexpr (KHEAD) {
+    // CONTRACT (the host launches this instance only then, launch_mlp): a wave's 32 rows span at most TWO groups -- A = 0 (K rows
+    // per group), A = 16, or A a multiple of 32 -- so one MFMA with K = 2 adds the group rows (rows are clamped to R - 1: g is
+    // monotone over the lanes).  Other A take the instance without KHEAD and its ob-outer stream.
+    gbase = ((long)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+    dg = (int)(g - gbase);
+    dg_last = __builtin_amdgcn_readlane(dg, 31);
+    const int k = half < dg_last ? half : dg_last;   // past the last group: its copy, times 0
+    const float* up = a.uproj + (gbase + k) * DE + j;
+    const float* qp = a.qproj + (gbase + k) * DH + j;
+    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { ua[ob] = up[ob * 32]; });
+    static_for<NHB>([&]<int ob>() QINCO_LAMBDA { qa[ob] = qp[ob * 32]; });
+    const float* tptr = a.ttab + (long)cid * DE + half * 4;
+    pptr = a.ptab + (long)cid * DH + half * 4;
+    static_for<LA>([&]<int i>() QINCO_LAMBDA { asm_load_block<i * 128>(yb[i], pptr); });
+    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = load_block(tptr + ob * 32); });
+  } else if constexpr (FOLD) {
     // ---- A-C folded: z = T[cid] + U[group] -----------------------------------------------------------
     // (hipcc turns these gathers into batches of 8 loads drained by vmcnt(0): 5 exposed round trips per tile with 288
     // registers, 12 under OCC2's 128-VGPR budget -- 74 k of a short-MLP tile's 226 k cycles, profiles/r02_timeline.jsonl.
@@ -432,7 +521,40 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
       skip_pad.template operator()<NEB * NHB * 4, SL.T_DOWN>();
       wp += SL.T_DOWN * 64;
     };
-    if constexpr (FOLD2) down_phase();   // block 0 (needs L >= 1: the host never picks FOLD2 for L == 0)
+    // KHEAD: block 0's down-projection, K-outer: y block ib = relu(P[cid] + Q[g]) is finished just before its 4 NEB fragments, block
+    // ib + LA is requested in its place; z = (T + U) + t at the end (the order of the ob-outer form)
+    auto first_down = [&]() QINCO_LAMBDA {
+      const float oh0 = (dg == half) ? 1.f : 0.f;
+      f32x16 t4[NEB];
+      static_for<NEB>([&]<int ob>() QINCO_LAMBDA { t4[ob] = zero16(); });
+      static_for<NHB>([&]<int ib>() QINCO_LAMBDA {
+        __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise moves the group add behind the next ring wait and drains vmcnt there)
+        // y block ib was requested LA blocks ago (ib < LA: in the head's burst, whose order is hipcc's: everything issued before
+        // this block's... first ring wait has to land); younger than its loads: NEB ring DMAs per block and the blocks after it
+        constexpr int YOUNGER = ib < LA ? NEB * ib + 4 * ib : NEB * LA + 4 * (LA - 1);
+        f32x16 yv = QINCO_MFMA(qa[ib], oh0, wait_block<YOUNGER>(yb[ib % LA]));
+        relu16(yv);
+        if constexpr (ib + LA < NHB) asm_load_block<(ib + LA) * 128>(yb[ib % LA], pptr);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<4>([&]<int q>() QINCO_LAMBDA {
+          static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+            constexpr int TI = (ib * 4 + q) * NEB + ob;
+            fragmm.template operator()<TI, q, khead_hosted(TI / 4)>(t4[ob], yv, noop);
+          });
+        });
+      });
+      static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
+        z[ob] = QINCO_MFMA(ua[ob], oh0, z[ob]);
+        z[ob] = z[ob] + t4[ob];
+        pin_v(z[ob]);
+      });
+      skip_pad.template operator()<NEB * NHB * 4, SL.T_DOWN>();
+      wp += SL.T_DOWN * 64;
+    };
+    if constexpr (KHEAD) {
+      first_down();
+      stamp(6);
+    } else if constexpr (FOLD2) down_phase();   // block 0 (needs L >= 1: the host never picks FOLD2 for L == 0)
 #pragma unroll 1
     for (int l = FOLD2 ? 1 : 0; l < a.L; ++l) {
       up_phase();
@@ -582,6 +704,62 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
       stamp(5);   // stores / tail DMAs retired
       return;
     }
+  }
+  if constexpr (KHEAD && !PROJ) {
+    // ---- E (KHEAD, identity projections): the same candidates and distances with every operand requested in ONE burst.  The
+    // generic epilogue below fetches a block's operands in front of its out_proj chain; without projections there is no chain and its
+    // four blocks were four exposed round trips at the end of the workgroup's life (28 k cycles, profiles/r03_timeline.jsonl).
+    // xhat (per group) and x (per vector) are the same bytes for every row of a group / vector: they arrive as one coalesced dword per
+    // lane and block and reach the rows through a one-hot MFMA, like the head's U and Q (o + 1 * xhat rounds like o + xhat; 1 * x + 0 is x).
+    const long nv = g / a.F;
+    const long nbase = ((long)__builtin_amdgcn_readfirstlane((int)(nv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)nv);
+    const int dn = (int)(nv - nbase), dn_last = __builtin_amdgcn_readlane(dn, 31);
+    float xha[NDB], xa[NDB];
+    {
+      const int kg = half < dg_last ? half : dg_last, kn = half < dn_last ? half : dn_last;
+      const float* hp = a.xhat + (gbase + kg) * D + j;
+      static_for<NDB>([&]<int ob>() QINCO_LAMBDA { xha[ob] = hp[ob * 32]; });
+      if (a.x) {
+        const float* xp = a.x + (nbase + kn) * D + j;
+        static_for<NDB>([&]<int ob>() QINCO_LAMBDA { xa[ob] = xp[ob * 32]; });
+      }
+    }
+    f32x16 cb4[NDB];
+    if (a.add_c) static_for<NDB>([&]<int ob>() QINCO_LAMBDA { cb4[ob] = load_block(cptr + ob * 32); });
+    const float ohg = (dg == half) ? 1.f : 0.f, ohn = (dn == half) ? 1.f : 0.f;
+    float* outp = a.cand_out + row * D + half * 4;
+    float s2 = 0.f, sx = 0.f, xn = 0.f;
+    static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
+      f32x16 o = z[ob];
+      if (a.add_c) o = o + cb4[ob];
+      o = QINCO_MFMA(xha[ob], ohg, o);
+      if (valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 t = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+          *reinterpret_cast<f32x4*>(outp + ob * 32 + 8 * q) = t;
+        }
+      }
+      if (a.x) {
+        f32x16 xb = QINCO_MFMA(xa[ob], ohn, zero16());
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {   // (the order of the generic epilogue: the same distances to the bit)
+          s2 = fmaf(o[i], o[i], s2);
+          sx = fmaf(o[i], xb[i], sx);
+          xn = fmaf(xb[i], xb[i], xn);
+        }
+      }
+    });
+    if (a.dist_out) {
+      s2 += __shfl_xor(s2, 32);
+      sx += __shfl_xor(sx, 32);
+      xn += __shfl_xor(xn, 32);
+      if (valid && half == 0) a.dist_out[row] = (xn + s2) - 2.f * sx;
+    }
+    stamp(4);
+    if constexpr (LDSR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(5);
+    return;
   }
   // ---- E: out_proj + epilogue: cand = (out + coeff*c) + xhat ; dist = |x|^2 + |cand|^2 - 2 x.cand
   const long n = g / a.F;

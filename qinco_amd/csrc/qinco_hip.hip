@@ -153,6 +153,11 @@ struct qinco_handle_s {
   StreamDims dec_sd{};
   // opt-in (QINCO_CREATE_EPILOGUE_SELECT): the encode instance with the per-vector top-T in its epilogue (VAR bit 2048, same weight stream)
   const MlpInstance* sel_inst = nullptr;
+  // production instance with KHEAD (VAR bit 4096): its twin without, for launches whose groups the KHEAD kernel does not take (a wave's
+  // 32 rows must span at most two groups: A >= 32 or A == 16) and for the epilogue-selection instance; alt_wstream = the same weights
+  // with block 0's down-projection ob-outer
+  const MlpInstance* alt_inst = nullptr;
+  std::vector<f32x4*> alt_wstream;
   std::vector<f32x4*> dec_wstream;
   // small-launch form (mlp_small_kernel.hpp): its weight stream (every step, contiguous), per-step table pointers, largest NT
   small_launch_fn small = nullptr;
@@ -245,7 +250,7 @@ static double mlp_flops_per_row(const qinco_handle_s* h) {
 //   FOLD:   R x (4 L De Dh + [De != D] 2 De D)  +  G x 2 D De                       (U = W_x xhat once per group);
 //   FOLD2:  R x ((4 L - 2) De Dh + [De != D] 2 De D)  +  G x (2 D De + 2 De Dh)     (Q = W_up[0] U too);
 //   decode in one launch of the small form: every row is its own group, U and Q are computed per row.
-static double mlp_flops_executed(const qinco_handle_s* h, double R, double G, bool folded, bool fold2) {
+static double mlp_flops_executed(const qinco_handle_s* h, double R, double G, bool folded, bool fold2, bool khead = false) {
   const qinco_desc& d = h->user;
   const double L = h->d.L;   // (a model without FFN blocks runs one all-zero block)
   if (!folded) return R * (2.0 * (d.De + d.D) * d.De + 4.0 * L * d.De * d.Dh + (d.De != d.D ? 4.0 * d.D * d.De : 0.0));
@@ -254,6 +259,14 @@ static double mlp_flops_executed(const qinco_handle_s* h, double R, double G, bo
   if (fold2) {
     per_row -= 2.0 * d.De * d.Dh;
     per_group += 2.0 * d.De * d.Dh;
+  }
+  if (khead && R > 0) {
+    // KHEAD: the per-group rows of the head are added by one 32x32x2 MFMA per 32-feature block and pair of groups of a wave's
+    // 32 rows (2 * 2 FLOPs per row and feature; padded dimensions: this is what the matrix pipe executes)
+    const double rows_per_group = R / (G > 0 ? G : 1);
+    int ng = rows_per_group >= 32 ? 1 : (int)((32 + rows_per_group - 1) / rows_per_group);
+    if (rows_per_group < 32 && ((int)rows_per_group == 0 || 32 % (int)rows_per_group != 0)) ng += 1;
+    per_row += 4.0 * (h->d.De + h->d.Dh) * ((ng + 1) / 2);
   }
   return R * per_row + G * per_group;
 }
@@ -1049,15 +1062,27 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   // measurement is long enough to be warm (C2 2.12 M against 2.08 M, qinco2-M 7.46 M against 6.92 M; scripts/exp_decode_twin.py):
   // round 2 had it the other way round from 10 ms timing loops.
   if (h->fold && (fn->var & 256) && !(create_flags & QINCO_CREATE_DECODE_FOLDED)) {
-    const MlpInstance* di = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~(16 | 32));
+    const MlpInstance* di = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~(16 | 32 | 4096));
     if (di && !(di->var & (16 | 32 | 128)) && di->P == fn->P) {
       h->dec_inst = di;
       h->dec_sd = stream_dims(d.D, d.De, d.Dh, di->P, false, false, 32);
     }
   }
+  if (fn && (fn->var & 4096)) {
+    // KHEAD takes launches whose groups are A >= 32 or A == 16 rows (mlp_kernel.hpp); every other launch, and the epilogue
+    // selection, runs on the twin without the bit, which reads block 0's down-projection ob-outer (alt_wstream)
+    const MlpInstance* ai = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var & ~4096);
+    if (!ai || ai->P != fn->P || ai->var != (fn->var & ~4096)) {
+      delete h;
+      return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: kernel instance (P=%d, VAR=%d) needs its twin VAR=%d for group sizes it does not take",
+                  fn->P, fn->var, fn->var & ~4096);
+    }
+    h->alt_inst = ai;
+  }
   if (fn && (create_flags & QINCO_CREATE_EPILOGUE_SELECT) && !(fn->var & 2048) && d.De == d.D && want_var < 0) {
-    const MlpInstance* si = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var | 2048);
-    if (si && si->P == fn->P && si->var == (fn->var | 2048)) h->sel_inst = si;
+    const int base = fn->var & ~4096;
+    const MlpInstance* si = find_mlp_instance(d.D, d.De, d.Dh, fn->P, base | 2048);
+    if (si && si->P == fn->P && si->var == (base | 2048)) h->sel_inst = si;
   }
   int rc = 0;
   auto bail = [&](int code) {
@@ -1082,6 +1107,7 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   h->sub_cnorm.assign(d.M, nullptr);
   h->wstream.assign(d.M, nullptr);
   h->dec_wstream.assign(d.M, nullptr);
+  h->alt_wstream.assign(d.M, nullptr);
   h->cb_stream.assign(d.M, nullptr);
   h->sub_stream.assign(d.M, nullptr);
   h->ttab.assign(d.M, nullptr);
@@ -1181,7 +1207,8 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
         continue;
       }
       if (!(h->fold2 && l == 0)) pack_obouter(s, up, d.Dh, d.De, sd.T_UP);
-      pack_obouter(s, dn, d.De, d.Dh, sd.T_DOWN);
+      if (h->fold2 && l == 0 && (fn->var & 4096)) pack_kouter(s, dn, d.De, d.Dh, sd.T_DOWN);   // KHEAD: block 0's down-projection K-outer
+      else pack_obouter(s, dn, d.De, d.Dh, sd.T_DOWN);
     }
     if (h->split16 && sd.PROJ && (d.D / 32) % 2 == 0) {   // = split_out_proj(D, De): out_proj in the split form, K-outer passes
       const float so = split_weight_scale(w->out_proj[m], (size_t)d.D * d.De);
@@ -1199,6 +1226,15 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
     float* ds = nullptr;
     if ((rc = upload(h, &ds, s.data(), s.size()))) return bail(rc);
     h->wstream[m] = reinterpret_cast<f32x4*>(ds);
+    if (h->alt_inst) {   // KHEAD's twin: block 0's down-projection (the stream's first section) ob-outer, the rest as it is
+      std::vector<float> t;
+      t.reserve(s.size());
+      pack_obouter(t, w->down[(size_t)m * d.L], d.De, d.Dh, sd.T_DOWN);
+      t.insert(t.end(), s.begin() + (size_t)sd.T_DOWN * 256, s.end());
+      float* dt = nullptr;
+      if ((rc = upload(h, &dt, t.data(), t.size()))) return bail(rc);
+      h->alt_wstream[m] = reinterpret_cast<f32x4*>(dt);
+    }
     if (h->dec_inst) {   // the complete stream (in_proj, bias, concat, every FFN block, out_proj) for the un-folded decode kernel
       const StreamDims& ds_ = h->dec_sd;
       std::vector<float> t;
@@ -1490,6 +1526,12 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
 #endif
   const int nt = decode ? 0 : small_nt(h, a.R, false);
   if (nt > 0 || !h->sel_inst || decode) a.sel_T = 0;   // (the epilogue selection lives in the 128-row encode kernel)
+  // the 128-row instance this launch takes; KHEAD only for groups of A >= 32 or A == 16 rows (a wave's 32 rows span at most two)
+  const MlpInstance* ran = unfolded ? h->dec_inst : (a.sel_T > 0 ? h->sel_inst : h->inst);
+  if (!unfolded && h->alt_inst && (a.sel_T > 0 || !(a.A >= 32 || a.A == 16))) {
+    if (a.sel_T == 0) ran = h->alt_inst;
+    a.wstream = h->alt_wstream[m];
+  }
   if (did_select) *did_select = a.sel_T > 0;
   if (nt > 0) {   // small launch: workgroups of 16 nt rows, same head (T + U, relu(P + Q)) and the same products in the same order
     SmallArgs sa{};
@@ -1511,12 +1553,13 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
     sa.dist_out = a.dist_out;
     HIP_TRY(h->small(&sa, 0, nt, st));
   } else {
-    HIP_TRY((unfolded ? h->dec_inst : (a.sel_T > 0 ? h->sel_inst : h->inst))->fn(&a, st));
+    HIP_TRY(ran->fn(&a, st));
   }
   if (h->prof) {
     HIP_TRY(hipEventRecord(e1, st));
     h->prof_flops += (double)a.R * mlp_flops_per_row(h);
-    h->prof_flops_exec += mlp_flops_executed(h, (double)a.R, (double)(a.R / a.A), h->fold && !unfolded, h->fold2 && !unfolded);
+    h->prof_flops_exec += mlp_flops_executed(h, (double)a.R, (double)(a.R / a.A), h->fold && !unfolded, h->fold2 && !unfolded,
+                                             nt == 0 && (ran->var & 4096));
   }
   return 0;
 }

@@ -21,7 +21,8 @@ cfg = BASELINE_CONFIGS[wl]
 sd = synth_state_dict(cfg, 1236)
 import os
 eng = QincoEngine(cfg, sd, max_batch=n, split_f16=bool(int(os.environ.get("QINCO_SPLIT_F16", "0"))),
-                  diagnostics={"epilogue_select": True} if not os.environ.get("QINCO_NO_SELEP") else None)
+                  diagnostics=({"mlp_variant": (48, int(os.environ["QINCO_VARIANT"]))} if os.environ.get("QINCO_VARIANT") else
+                               {"epilogue_select": True} if not os.environ.get("QINCO_NO_SELEP") else None))
 x = torch.from_numpy(synth_vectors(cfg, sd, n, seed=1)).cuda()
 lib = eng.lib
 lib.qinco_debug_timeline.restype = C.c_long

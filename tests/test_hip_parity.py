@@ -487,6 +487,37 @@ def test_epilogue_selection_is_bit_identical_to_beam_select(shape, A, B):
     plain.close()
 
 
+@pytest.mark.parametrize("model,A,B", [("qinco2-S", 16, 8), ("qinco2-S", 16, 1), ("qinco2-S", 32, 4), ("qinco2-S", 64, 2), ("qinco2-S", 8, 8),
+                                       ("qinco2-S", 20, 4), ("qinco2-S", 1, 1), ("qinco1", 0, 1)])
+def test_khead_instance_is_bit_identical_to_its_twin(model, A, B):
+    """The production instance of the BigANN short-MLP shape (csrc/mlp_kernel.hpp KHEAD, VAR bit 4096) adds the head's per-group rows
+    with one-hot MFMAs, runs block 0's down-projection K-outer under the gathers of its y blocks (inline-asm loads with hand-counted
+    waits: a race detector as much as a numerics check) and requests the epilogue's operands in one burst.  Every product is added in
+    the order of the twin without the bit (VAR 380, the production instance of rounds 2-3): codes AND tracked reconstructions must be
+    the same bits -- for the group sizes KHEAD takes itself (A = 16, A >= 32, A = 0: K rows per group) and for those the library routes to
+    the twin and its ob-outer stream (A = 8, 20, 1) -- with duplicated rows, a partly empty last workgroup, and run to run."""
+    import torch
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    from qinco_amd.config import preset
+    cfg = preset(model, D=128, M=4, A=A, B=B) if model != "qinco1" else preset(model, D=128, M=3, L=4)
+    sd = synth_state_dict(cfg, 4476)
+    n = 20000 if model != "qinco1" else 3000
+    x = synth_vectors(cfg, sd, n, seed=44)
+    x[100:200] = x[0:100]
+    xd = torch.from_numpy(x).cuda()
+    khead = QincoEngine(cfg, sd, max_batch=n)
+    assert "var=4476" in khead.describe(), khead.describe()
+    twin = QincoEngine(cfg, sd, max_batch=n, diagnostics={"mlp_variant": (48, 380)})
+    for m in (n, n // 2 + 1, 4097):
+        ck, hk = khead.encode(xd[:m], return_xhat=True)
+        ct, ht = twin.encode(xd[:m], return_xhat=True)
+        assert torch.equal(ck, ct) and torch.equal(hk, ht), m
+        ck2, hk2 = khead.encode(xd[:m], return_xhat=True)
+        assert torch.equal(ck, ck2) and torch.equal(hk, hk2), m
+    khead.close()
+    twin.close()
+
+
 @pytest.mark.parametrize("model,D", [("qinco2-S", 128), ("qinco2-M", 128), ("qinco1", 128)])
 def test_codes_do_not_depend_on_max_batch(model, D):
     """The same vectors through handles of different max_batch take different kernels (small passes: cooperative / fused

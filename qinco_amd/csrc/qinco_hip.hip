@@ -267,6 +267,8 @@ static double mlp_flops_executed(const qinco_handle_s* h, double R, double G, bo
     int ng = rows_per_group >= 32 ? 1 : (int)((32 + rows_per_group - 1) / rows_per_group);
     if (rows_per_group < 32 && ((int)rows_per_group == 0 || 32 % (int)rows_per_group != 0)) ng += 1;
     per_row += 4.0 * (h->d.De + h->d.Dh) * ((ng + 1) / 2);
+    // ... and, without projections, its epilogue adds xhat and lays x out the same way: 2 x one MFMA per block (encode: x is given)
+    if (h->d.De == h->d.D) per_row += 8.0 * h->d.D;
   }
   return R * per_row + G * per_group;
 }

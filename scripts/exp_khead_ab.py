@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("workloads", nargs="*", default=["S", "C1"])
 ap.add_argument("--beam", type=int, nargs=2, action="append", default=None, help="extra (A, B) overrides to check for identity")
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--variants", type=int, nargs="*", default=[4476, 380])
+ap.add_argument("--variants", nargs="*", default=["48:4476", "48:380"], help="P:VAR kernel instances")
 args = ap.parse_args()
 for wl in args.workloads:
     cfg = BASELINE_CONFIGS[wl]
@@ -22,7 +22,7 @@ for wl in args.workloads:
     codes = {}
     for var in args.variants:
         for mb in (16384, 1024):
-            eng = QincoEngine(cfg, sd, max_batch=mb, diagnostics={"mlp_variant": (48, var)})
+            eng = QincoEngine(cfg, sd, max_batch=mb, diagnostics={"mlp_variant": tuple(int(v) for v in var.split(":"))})
             if mb == 16384:
                 print(wl, var, eng.describe() if hasattr(eng, "describe") else "", flush=True)
             eng.encode(x[:mb], code_dtype=np.uint8); torch.cuda.synchronize()

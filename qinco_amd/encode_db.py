@@ -207,13 +207,14 @@ class PartFileWriter:
     numpy deflates the 8 N M bytes of a part file on one core at the end of the job: 2.4-4.6 s per million vectors -- nothing
     next to the reference's CPU encode, but MORE than the whole GPU encode of a qinco2-S model (1.5 s per million).  Same file
     format here -- a zip with one deflated member `codes.npy`, readable by np.load, by the reference's EncodedDBIterator
-    (search_utils.py:33-78) and by zipfile's CRC check -- produced pigz-style: the .npy byte stream is cut into 4 MiB chunks,
+    (search_utils.py:33-78) and by zipfile's CRC check -- produced pigz-style: the .npy byte stream is cut into 1 MiB chunks (one batch of 65 536 x 8 codes = 4 of them: the
+    tail behind the last batch deflates on 4 threads, not on one),
     each deflated independently on a thread pool (zlib releases the GIL) and closed with a sync flush, so that their
     concatenation is ONE valid raw-deflate stream; chunks are compressed while later batches are still being encoded.
     rows / M must be known up front (the .npy header comes first in the stream); zip64 records are always written (numpy
     does the same: force_zip64)."""
 
-    CHUNK = 4 << 20
+    CHUNK = 1 << 20
 
     def __init__(self, path: str, rows: int, M: int, threads: int = 8, level: int = 6):
         import concurrent.futures as cf

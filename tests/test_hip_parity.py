@@ -487,10 +487,11 @@ def test_epilogue_selection_is_bit_identical_to_beam_select(shape, A, B):
     plain.close()
 
 
-@pytest.mark.parametrize("model,A,B", [("qinco2-S", 16, 8), ("qinco2-S", 16, 1), ("qinco2-S", 32, 4), ("qinco2-S", 64, 2), ("qinco2-S", 8, 8),
-                                       ("qinco2-S", 20, 4), ("qinco2-S", 1, 1), ("qinco1", 0, 1)])
-def test_khead_instance_is_bit_identical_to_its_twin(model, A, B):
-    """The production instance of the BigANN short-MLP shape (csrc/mlp_kernel.hpp KHEAD, VAR bit 4096) adds the head's per-group rows
+@pytest.mark.parametrize("model,A,B,D", [("qinco2-S", 16, 8, 128), ("qinco2-S", 16, 1, 128), ("qinco2-S", 32, 4, 128), ("qinco2-S", 64, 2, 128),
+                                         ("qinco2-S", 8, 8, 128), ("qinco2-S", 20, 4, 128), ("qinco2-S", 1, 1, 128), ("qinco1", 0, 1, 128),
+                                         ("qinco1", 0, 1, 96), ("qinco2-S", 16, 8, 96), ("qinco2-S", 16, 4, 256), ("qinco2-S", 16, 8, 768)])
+def test_khead_instance_is_bit_identical_to_its_twin(model, A, B, D):
+    """The production instance of the short-MLP shapes -- every dataset dimension, with and without projections -- (csrc/mlp_kernel.hpp KHEAD, VAR bit 4096) adds the head's per-group rows
     with one-hot MFMAs, runs block 0's down-projection K-outer under the gathers of its y blocks (inline-asm loads with hand-counted
     waits: a race detector as much as a numerics check) and requests the epilogue's operands in one burst.  Every product is added in
     the order of the twin without the bit (VAR 380, the production instance of rounds 2-3): codes AND tracked reconstructions must be
@@ -499,9 +500,9 @@ def test_khead_instance_is_bit_identical_to_its_twin(model, A, B):
     import torch
     from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
     from qinco_amd.config import preset
-    cfg = preset(model, D=128, M=4, A=A, B=B) if model != "qinco1" else preset(model, D=128, M=3, L=4)
+    cfg = preset(model, D=D, M=4, A=A, B=B) if model != "qinco1" else preset(model, D=D, M=3, L=4)
     sd = synth_state_dict(cfg, 4476)
-    n = 20000 if model != "qinco1" else 3000
+    n = (20000 if D <= 128 else 6000) if model != "qinco1" else 3000
     x = synth_vectors(cfg, sd, n, seed=44)
     x[100:200] = x[0:100]
     xd = torch.from_numpy(x).cuda()

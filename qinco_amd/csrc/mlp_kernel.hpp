@@ -142,6 +142,9 @@ QINCO_INL f32x16 wait_block(AsmBlock& b) {   // "at most N vector-memory operati
   return v;
 }
 
+#ifndef QINCO_KHEAD_LA
+#define QINCO_KHEAD_LA 2
+#endif
 template <int D, int DE, int DH, int P, int VAR>
 __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a) {
   constexpr bool FOLD = (VAR & 16) != 0;
@@ -199,7 +202,10 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   }
 #endif
   const long g = row / a.A;
-  const int cid = a.cand_ids ? a.cand_ids[row] : (int)(row - g * a.A);
+  int cid = a.cand_ids ? a.cand_ids[row] : (int)(row - g * a.A);
+  // KHEAD: the candidate id has ARRIVED before the ring prologue's DMAs go out.  hipcc otherwise waits for it at its first use, behind
+  // the DMAs -- and a wait it generates with ring DMAs in flight is vmcnt(0): the prologue's round trip in front of the head's burst
+  if constexpr ((VAR & 4096) != 0) asm volatile("" : "+v"(cid)::"memory");
   const float* cptr = a.codebook + (long)cid * D + half * 4;
   const float* xhptr = a.xhat + g * D + half * 4;
 
@@ -236,6 +242,43 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
     asm volatile("" ::: "memory");
   };
+  f32x16 z[NEB];
+  f32x16 y[NYB];
+  // KHEAD: state that lives from the head into the first down-projection
+  constexpr int LA = QINCO_KHEAD_LA;   // y blocks in flight ahead of the matrix pipe
+  constexpr int KHEAD_BURST = NEB + NHB + 4 * (LA + NEB);   // vector-memory loads of the head's burst
+  // Gathers in flight at the ring wait of group G of the first down-projection (see take): the DMA that wait is for was issued at
+  // group G + 2 - P / 4 (in the ring prologue for G <= P / 4 - 3).  Issued since then: the head's burst (NEB + NHB dwords, LA + NEB blocks of 4
+  // loads; only while G <= 9) and the 4 loads of y block ib + LA, requested in front of group 4 NEB ib / 4 ... = block ib's first group
+  // (NEB groups per block), for every ib < NHB - LA with  first <= G <= first + P / 4 - 3.
+  constexpr auto khead_hosted = [](int G) constexpr {
+    int n = G <= P / 4 - 3 ? KHEAD_BURST : 0;
+    for (int ib = 0; ib + LA < NHB; ++ib)
+      if (NEB * ib <= G && G <= NEB * ib + P / 4 - 3) n += 4;
+    return n;
+  };
+  [[maybe_unused]] AsmBlock yb[KHEAD ? LA : 1];
+  [[maybe_unused]] float ua[NEB], qa[NHB];   // (dead registers outside KHEAD)
+  [[maybe_unused]] long gbase = 0;
+  [[maybe_unused]] int dg = 0, dg_last = 0;
+  [[maybe_unused]] const float* pptr = nullptr;
+  auto khead_burst = [&]() QINCO_LAMBDA {
+    // CONTRACT (the host launches this instance only then, launch_mlp): a wave's 32 rows span at most TWO groups -- A = 0 (K rows
+    // per group), A = 16, or A a multiple of 32 -- so one MFMA with K = 2 adds the group rows (rows are clamped to R - 1: g is
+    // monotone over the lanes).  Other A take the instance without KHEAD and its ob-outer stream.
+    gbase = ((long)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+    dg = (int)(g - gbase);
+    dg_last = __builtin_amdgcn_readlane(dg, 31);
+    const int k = half < dg_last ? half : dg_last;   // past the last group: its copy, times 0
+    const float* up = a.uproj + (gbase + k) * DE + j;
+    const float* qp = a.qproj + (gbase + k) * DH + j;
+    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { ua[ob] = up[ob * 32]; });
+    static_for<NHB>([&]<int ob>() QINCO_LAMBDA { qa[ob] = qp[ob * 32]; });
+    const float* tptr = a.ttab + (long)cid * DE + half * 4;
+    pptr = a.ptab + (long)cid * DH + half * 4;
+    static_for<LA>([&]<int i>() QINCO_LAMBDA { asm_load_block<i * 128>(yb[i], pptr); });
+    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = load_block(tptr + ob * 32); });
+  };
   if constexpr (SHR && G8) {
     // fragments 0 .. P-9 are issued (P/4 - 2 per wave); "<= P/4 - 3 outstanding" = every wave's first one landed
     static_for<P / 4 - 2>([&]<int i>() QINCO_LAMBDA { dma.template operator()<4 * i>(); });
@@ -246,7 +289,10 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   } else if constexpr (SHR) {
     // fragments 0 .. P-5 are issued (P/4 - 1 per wave); "<= P/4 - 2 outstanding" = every wave's first one landed
     static_for<P / 4 - 1>([&]<int i>() QINCO_LAMBDA { dma.template operator()<4 * i>(); });
-    wait_vm.template operator()<P / 4 - 2>();
+    // KHEAD: the head's gathers go out behind the prologue's DMAs, so that the two round trips overlap; the wait for the first
+    // fragment leaves them in flight (they are younger than every DMA issued so far)
+    if constexpr (KHEAD) khead_burst();
+    wait_vm.template operator()<P / 4 - 2 + (KHEAD ? KHEAD_BURST : 0)>();
     __builtin_amdgcn_s_barrier();
     ring[0] = myring[lane];
     ring[1] = myring[64 + lane];
@@ -322,42 +368,9 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
     extra();
   };
 
-  f32x16 z[NEB];
-  f32x16 y[NYB];
 
-  // KHEAD: state that lives from the head into the first down-projection
-  constexpr int LA = 2;   // y blocks in flight ahead of the matrix pipe
-  // Gathers in flight at the ring wait of group G of the first down-projection (see take): the DMA that wait is for was issued at
-  // group G + 2 - P / 4 (in the ring prologue for G <= P / 4 - 3).  Issued since then: the head's burst (NEB + NHB dwords, LA + NEB blocks of 4
-  // loads; only while G <= 9) and the 4 loads of y block ib + LA, requested in front of group 4 NEB ib / 4 ... = block ib's first group
-  // (NEB groups per block), for every ib < NHB - LA with  first <= G <= first + P / 4 - 3.
-  constexpr auto khead_hosted = [](int G) constexpr {
-    int n = G <= P / 4 - 3 ? NEB + NHB + 4 * (LA + NEB) : 0;
-    for (int ib = 0; ib + LA < NHB; ++ib)
-      if (NEB * ib <= G && G <= NEB * ib + P / 4 - 3) n += 4;
-    return n;
-  };
-  [[maybe_unused]] AsmBlock yb[KHEAD ? LA : 1];
-  [[maybe_unused]] float ua[NEB], qa[NHB];   // (dead registers outside KHEAD)
-  [[maybe_unused]] long gbase = 0;
-  [[maybe_unused]] int dg = 0, dg_last = 0;
-  [[maybe_unused]] const float* pptr = nullptr;
   if constexpr (KHEAD) {
-    // CONTRACT (the host launches this instance only then, launch_mlp): a wave's 32 rows span at most TWO groups -- A = 0 (K rows
-    // per group), A = 16, or A a multiple of 32 -- so one MFMA with K = 2 adds the group rows (rows are clamped to R - 1: g is
-    // monotone over the lanes).  Other A take the instance without KHEAD and its ob-outer stream.
-    gbase = ((long)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)g);
-    dg = (int)(g - gbase);
-    dg_last = __builtin_amdgcn_readlane(dg, 31);
-    const int k = half < dg_last ? half : dg_last;   // past the last group: its copy, times 0
-    const float* up = a.uproj + (gbase + k) * DE + j;
-    const float* qp = a.qproj + (gbase + k) * DH + j;
-    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { ua[ob] = up[ob * 32]; });
-    static_for<NHB>([&]<int ob>() QINCO_LAMBDA { qa[ob] = qp[ob * 32]; });
-    const float* tptr = a.ttab + (long)cid * DE + half * 4;
-    pptr = a.ptab + (long)cid * DH + half * 4;
-    static_for<LA>([&]<int i>() QINCO_LAMBDA { asm_load_block<i * 128>(yb[i], pptr); });
-    static_for<NEB>([&]<int ob>() QINCO_LAMBDA { z[ob] = load_block(tptr + ob * 32); });
+    // (the head's burst was issued in front of the ring prologue's wait: khead_burst)
   } else if constexpr (FOLD) {
     // ---- A-C folded: z = T[cid] + U[group] -----------------------------------------------------------
     // (hipcc turns these gathers into batches of 8 loads drained by vmcnt(0): 5 exposed round trips per tile with 288

@@ -206,6 +206,11 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   // KHEAD: the candidate id has ARRIVED before the ring prologue's DMAs go out.  hipcc otherwise waits for it at its first use, behind
   // the DMAs -- and a wait it generates with ring DMAs in flight is vmcnt(0): the prologue's round trip in front of the head's burst
   if constexpr ((VAR & 4096) != 0) asm volatile("" : "+v"(cid)::"memory");
+#if defined(QINCO_EXPERIMENT) && defined(QINCO_EXP_FEW_LINES)
+  // experiment builds (WRONG results, timing only): every row gathers the same few table rows and stores to the same few candidate
+  // rows -- a gather / store instruction then touches 1-4 cache lines instead of 64: what the vector L1's look-up rate costs
+  cid &= (QINCO_EXP_FEW_LINES & 1) ? 1 : 0xffff;
+#endif
   const float* cptr = a.codebook + (long)cid * D + half * 4;
   const float* xhptr = a.xhat + g * D + half * 4;
 
@@ -740,7 +745,11 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
     f32x16 cb4[NDB];
     if (a.add_c) static_for<NDB>([&]<int ob>() QINCO_LAMBDA { cb4[ob] = load_block(cptr + ob * 32); });
     const float ohg = (dg == half) ? 1.f : 0.f, ohn = (dn == half) ? 1.f : 0.f;
+#if defined(QINCO_EXPERIMENT) && defined(QINCO_EXP_FEW_LINES)
+    float* outp = a.cand_out + ((QINCO_EXP_FEW_LINES & 2) ? (row & 1) : row) * D + half * 4;
+#else
     float* outp = a.cand_out + row * D + half * 4;
+#endif
     float s2 = 0.f, sx = 0.f, xn = 0.f;
     static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
       f32x16 o = z[ob];

@@ -116,6 +116,12 @@ QINCO_INL void pin_v(f32x16& v) { asm volatile("" : "+v"(v)); }
 QINCO_INL void pin4_v(f32x4& v) { asm volatile("" : "+v"(v)); }
 QINCO_INL void pin_a(f32x16& v) { asm volatile("" : "+a"(v)); }
 
+// A operand of a one-hot MFMA (KHEAD): the row of ANOTHER group rides in the same instruction and is multiplied by 0 for this wave's
+// other rows -- which is only exact for finite values (0 * inf = NaN would poison the neighbouring group, i.e. another vector's rows,
+// which the reference's row-by-row arithmetic never does).  v_med3_f32 against +-FLT_MAX returns every finite value unchanged and
+// turns inf / NaN into +-FLT_MAX: a vector with non-finite inputs keeps garbage results of its own, its neighbours keep theirs.
+QINCO_INL float one_hot_operand(float v) { return __builtin_amdgcn_fmed3f(v, -3.4028234663852886e38f, 3.4028234663852886e38f); }
+
 // A 32-feature block of a table row requested by loads hipcc does not see as loads (KHEAD).  hipcc's wait-count pass treats every
 // LDS-DMA of the weight ring as a "flat" access that may complete out of order, so any wait IT generates for a global load while
 // a ring DMA is in flight is vmcnt(0): the whole ring and every other gather drained (that is what made the head's 12 batches 12
@@ -550,7 +556,7 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
         // y block ib was requested LA blocks ago (ib < LA: in the head's burst, whose order is hipcc's: everything issued before
         // this block's... first ring wait has to land); younger than its loads: NEB ring DMAs per block and the blocks after it
         constexpr int YOUNGER = ib < LA ? NEB * ib + 4 * ib : NEB * LA + 4 * (LA - 1);
-        f32x16 yv = QINCO_MFMA(qa[ib], oh0, wait_block<YOUNGER>(yb[ib % LA]));
+        f32x16 yv = QINCO_MFMA(one_hot_operand(qa[ib]), oh0, wait_block<YOUNGER>(yb[ib % LA]));
         relu16(yv);
         if constexpr (ib + LA < NHB) asm_load_block<(ib + LA) * 128>(yb[ib % LA], pptr);
         __builtin_amdgcn_sched_barrier(0);
@@ -562,7 +568,7 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
         });
       });
       static_for<NEB>([&]<int ob>() QINCO_LAMBDA {
-        z[ob] = QINCO_MFMA(ua[ob], oh0, z[ob]);
+        z[ob] = QINCO_MFMA(one_hot_operand(ua[ob]), oh0, z[ob]);
         z[ob] = z[ob] + t4[ob];
         pin_v(z[ob]);
       });
@@ -754,7 +760,7 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
     static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
       f32x16 o = z[ob];
       if (a.add_c) o = o + cb4[ob];
-      o = QINCO_MFMA(xha[ob], ohg, o);
+      o = QINCO_MFMA(one_hot_operand(xha[ob]), ohg, o);
       if (valid) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -763,7 +769,7 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
         }
       }
       if (a.x) {
-        f32x16 xb = QINCO_MFMA(xa[ob], ohn, zero16());
+        f32x16 xb = QINCO_MFMA(one_hot_operand(xa[ob]), ohn, zero16());
 #pragma unroll
         for (int i = 0; i < 16; ++i) {   // (the order of the generic epilogue: the same distances to the bit)
           s2 = fmaf(o[i], o[i], s2);

@@ -519,6 +519,35 @@ def test_khead_instance_is_bit_identical_to_its_twin(model, A, B, D):
     twin.close()
 
 
+@pytest.mark.parametrize("B", [1, 8])
+def test_non_finite_rows_do_not_touch_their_neighbours(B):
+    """The reference's arithmetic is row by row: a vector of NaNs or infinities gets garbage codes, its neighbours are not affected.
+    KHEAD brings a group's x / xhat / U / Q rows to its candidates through a one-hot MFMA, in which the OTHER group of the wave -- with
+    B = 1 another vector -- is multiplied by 0: exact only for finite values, so the operand is clamped to +-FLT_MAX
+    (csrc/mlp_kernel.hpp one_hot_operand).  Every other row's codes must be those of the clean batch, every code in range."""
+    from qinco_amd import QincoEngine, synth_state_dict, synth_vectors
+    from qinco_amd.config import preset
+    cfg = preset("qinco2-S", D=128, M=4, A=16, B=B)
+    sd = synth_state_dict(cfg, 99)
+    n = 6000
+    x = synth_vectors(cfg, sd, n, seed=12)
+    eng = QincoEngine(cfg, sd, max_batch=n)
+    assert "var=4476" in eng.describe()
+    clean = eng.encode(x)
+    bad = [7, 1000, 1001, 4095, n - 1]
+    x[7, :] = np.nan
+    x[1000, 5] = np.inf
+    x[1001, :] = -np.inf
+    x[4095, ::2] = np.nan
+    x[n - 1, 0] = np.nan
+    codes = eng.encode(x)
+    assert codes.min() >= 0 and codes.max() < cfg.K
+    keep = np.ones(n, bool)
+    keep[bad] = False
+    assert np.array_equal(codes[keep], clean[keep]), int((codes[keep] != clean[keep]).any(axis=1).sum())
+    eng.close()
+
+
 @pytest.mark.parametrize("model,D", [("qinco2-S", 128), ("qinco2-M", 128), ("qinco1", 128)])
 def test_codes_do_not_depend_on_max_batch(model, D):
     """The same vectors through handles of different max_batch take different kernels (small passes: cooperative / fused

@@ -127,14 +127,14 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
 
 def instance_plan(Dp: int, Dep: int, Dhp: int) -> tuple[int, int]:
     """(P, VAR) of the kernel form that serves a padded shape (csrc/shapes.def explains the VAR bits): the 32-row kernel with the
-    folded head -- two workgroups per CU on the short shapes -- while its activations fit the register file (z = De / 2 VGPRs,
+    folded head -- two workgroups per CU with KHEAD on the short shapes -- while its activations fit the register file (z = De / 2 VGPRs,
     y = Dh / 2 AGPRs per lane: De <= 384, Dh <= 512, De + Dh <= 768; (256, 512) compiles to 236 VGPRs + 256 AGPRs, no
     scratch), else the 16-row tile kernel."""
     if Dp > 1024:
         raise NotImplementedError(f"no kernel form for D={Dp}: the per-group pre-GEMM keeps a group's D / 32 input blocks in registers "
                                   "(D <= 1024; the reference's widest dataset is 768)")
     if Dep <= 384 and Dhp <= 512 and Dep + Dhp <= 768:
-        return (48, 380) if (Dep <= 128 and Dhp <= 256) else (48, 124)
+        return (48, 4476) if (Dep <= 128 and Dhp <= 256) else (48, 124)     # (short shapes: two workgroups per CU + KHEAD)
     if Dep <= 768 and max(Dep, Dhp) <= 1024:
         return (48, 1236)     # 16-row tile form, ring groups of 8, folded head
     raise NotImplementedError(f"no kernel form for De={Dep}, Dh={Dhp}: the 16-row tile kernel holds De/4 + max(De, Dh)/4 registers "
@@ -169,7 +169,8 @@ def ensure_instance(D: int, De: int, Dh: int, verbose: bool = False) -> Path | N
         inst_dir.mkdir(parents=True, exist_ok=True)
     # the encode instance, and -- for the two-workgroups-per-CU forms -- the un-folded twin decode runs on (DESIGN.md 3.1:
     # faster there, slower on the wide shapes); compiled side by side
-    variants = [var] + ([var & ~(16 | 32 | 4096)] if (var & 16) and (var & 256) else [])   # (the twin pays on the OCC2 shapes only)
+    # (KHEAD needs its twin without the bit for the group sizes it does not take; the un-folded decode twin pays on the OCC2 shapes only)
+    variants = [var] + ([var & ~4096] if var & 4096 else []) + ([var & ~(16 | 32 | 4096)] if (var & 16) and (var & 256) else [])
     jobs = []
     for v in variants:
         so = inst_dir / f"inst_{Dp}_{Dep}_{Dhp}_{P}_{v}.so"

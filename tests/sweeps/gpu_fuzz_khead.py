@@ -20,7 +20,18 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
+ODD = False    # --odd: the short geometries served by kernel instances built on demand (zero-padded to 32-feature blocks: 3 / 4 blocks of
+               # De, 5 / 7 of Dh), which take the same plan
+
+
 def draw(rs):
+    if ODD:
+        D, de, dh = [(100, None, 200), (64, 96, 160), (100, None, 200)][int(rs.randint(3))]
+        qinco1 = de is None and rs.rand() < 0.25
+        A = 0 if qinco1 else int(rs.choice([8, 16, 16, 32, 64]))
+        B = 1 if qinco1 else int(rs.choice([1, 4, 8]))
+        return dict(cfg=dict(D=D, M=int(rs.choice([2, 3])), K=256, L=int(rs.choice([1, 2, 3])), de=de, dh=dh, A=A, B=B, qinco1_mode=qinco1),
+                    n=int(rs.choice([1500, 2100, 3001])), rebeam=None, u8=False)
     D = int(rs.choice([96, 128, 128, 128, 256, 768]))
     qinco1 = D in (96, 128) and rs.rand() < 0.25
     de = None if (qinco1 or (D in (96, 128) and rs.rand() < 0.5)) else 128
@@ -42,7 +53,14 @@ def main() -> int:
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--count", type=int, default=24)
     ap.add_argument("--out", default="")
+    ap.add_argument("--odd", action="store_true")
     a = ap.parse_args()
+    global ODD
+    ODD = a.odd
+    if ODD:
+        from qinco_amd.build import ensure_instance
+        for shape in ((100, 100, 200), (64, 96, 160)):
+            ensure_instance(*shape)
     from conftest import assert_only_near_ties, make_oracle
     from qinco_amd import QincoConfig, QincoEngine, apply_regime, regime_vectors, synth_state_dict, synth_vectors
     NEAR_TIE, REL_TOL = 2e-5, 1e-5
@@ -67,6 +85,7 @@ def main() -> int:
             rec["describe"] = eng.describe()
             assert "var=4476" in rec["describe"], rec["describe"]
             twin = QincoEngine(cfg, sd, max_batch=4096, diagnostics={"mlp_variant": (48, 380)})
+            assert "var=380" in twin.describe(), twin.describe()
             if c["rebeam"]:
                 A2, B2 = c["rebeam"]
                 eng.set_beam(A=A2, B=B2)

@@ -136,7 +136,7 @@ def test_kernel_instance_built_on_demand_and_registered(lib):
     assert lib.qinco_padded_shape(100, 128, 256, out3) == 0 and list(out3) == [128, 160, 256]     # projections must survive
     assert lib.qinco_padded_shape(100, 100, 256, out3) == 0 and list(out3) == [128, 128, 256]     # QINCo1: De == D stays
     assert lib.qinco_shape_supported(100, 100, 256) == 1                                          # = the compiled-in C1 shape
-    assert instance_plan(128, 256, 512) == (48, 124) and instance_plan(128, 128, 224) == (48, 380)
+    assert instance_plan(128, 256, 512) == (48, 124) and instance_plan(128, 128, 224) == (48, 4476)
     assert instance_plan(224, 224, 320) == (48, 124) and instance_plan(128, 512, 384) == (48, 1236)   # De > 384: 16-row tile form
     with pytest.raises(NotImplementedError):
         instance_plan(128, 1024, 256)

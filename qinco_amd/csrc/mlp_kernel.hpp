@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   f32x16 z[NEB];
   f32x16 y[NYB];
   // KHEAD: state that lives from the head into the first down-projection
-  constexpr int LA = QINCO_KHEAD_LA;   // y blocks in flight ahead of the matrix pipe
+  constexpr int LA = QINCO_KHEAD_LA < SL.NHB ? QINCO_KHEAD_LA : SL.NHB;   // y blocks in flight ahead of the matrix pipe (a P row has NHB of them)
   constexpr int KHEAD_BURST = NEB + NHB + 4 * (LA + NEB);   // vector-memory loads of the head's burst
   // Gathers in flight at the ring wait of group G of the first down-projection (see take): the DMA that wait is for was issued at
   // group G + 2 - P / 4 (in the ring prologue for G <= P / 4 - 3).  Issued since then: the head's burst (NEB + NHB dwords, LA + NEB blocks of 4

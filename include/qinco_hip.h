@@ -106,11 +106,12 @@ enum {
   QINCO_CREATE_SPLIT_NO_CALIBRATION = 32,  /* skip the create-time comparison with the fp32 instance (below) */
   QINCO_CREATE_NO_PRESEL_FUSION = 64,      /* diagnostics: pre-selection table and xproj as two launches at every launch size */
   QINCO_CREATE_NO_SMALL_LAUNCH = 128,      /* diagnostics: the 128-rows-per-workgroup kernels at every launch size */
-  QINCO_CREATE_EPILOGUE_SELECT = 256       /* opt-in (measured slower, off by default): identity-projection models whose F * A candidates per
-                                              vector fit a 128-row workgroup take the step's per-vector top-B in the fused-MLP kernel's
-                                              epilogue (csrc/mlp_kernel.hpp SELEP) -- no candidate / distance write-back, no beam_select
-                                              launch, bit-identical codes; the longer end of a workgroup's life costs more than the
-                                              write-back it saves: qinco2-S 635 k against 672 k vectors/s */
+  QINCO_CREATE_EPILOGUE_SELECT = 256,      /* identity-projection models whose F * A candidates per vector fit a 128-row workgroup take the step's
+                                              per-vector top-B in the fused-MLP kernel's epilogue (csrc/mlp_kernel.hpp SELEP): no candidate /
+                                              distance write-back, no beam_select launch, bit-identical codes.  On by default where the shape
+                                              has the KHEAD + SELEP instance (qinco2-S / QINCo1 with A > 0 on 128-d data: +2 %);
+                                              this flag asks for it on the other identity-projection shapes that have a SELEP instance */
+  QINCO_CREATE_NO_EPILOGUE_SELECT = 512    /* diagnostics: never (the two-kernel form: candidate write-back + beam_select_kernel) */
 };
 
 /* The split form checks itself.  (1) At create, unless QINCO_CREATE_SPLIT_NO_CALIBRATION: the model is also built as an fp32

@@ -13,6 +13,7 @@ CODE_I64, CODE_I32, CODE_U8 = 0, 1, 2
 FLAG_NORMALISED = 1
 CREATE_SPLIT_F16, CREATE_IVF_FP32, CREATE_TABLE_VALU, CREATE_DECODE_FOLDED, CREATE_TABLE_NO_COOP = 1, 2, 4, 8, 16
 CREATE_SPLIT_NO_CALIBRATION, CREATE_NO_PRESEL_FUSION, CREATE_NO_SMALL_LAUNCH, CREATE_EPILOGUE_SELECT = 32, 64, 128, 256
+CREATE_NO_EPILOGUE_SELECT = 512
 
 # every symbol include/qinco_hip.h declares (tests check the library exports all of them)
 API_SYMBOLS = [

@@ -236,7 +236,10 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   const f32x4* wp = a.wstream + lane;
   constexpr int NRING = LDSR ? 3 : P;
   f32x4 ring[NRING];
-  __shared__ f32x4 lds_ring[LDSR ? (SHR ? 1 : 4) * P * 64 : 1];
+  // (SELEP's keys and indices live in the tail of this array: a SECOND __shared__ object in the kernel makes hipcc order the ring's
+  // LDS reads behind the LDS-DMAs in flight -- s_waitcnt vmcnt(0) in front of 142 of them in the SELEP instance of rounds 3-4)
+  constexpr int RING4 = LDSR ? (SHR ? 1 : 4) * P * 64 : 1;
+  __shared__ f32x4 lds_ring[RING4 + (((VAR & 2048) != 0) ? 96 : 0)];
   [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   [[maybe_unused]] f32x4* myring = lds_ring + ((LDSR && !SHR) ? wave_u * P * 64 : 0);
   // DMA of fragment T (relative to the current section origin wp) into its ring slot.  SHR: T is a multiple of 4
@@ -629,19 +632,21 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
         for (int jj = 0; jj < HP; ++jj) hv[jj] = jj < a.sel_m ? a.sel_hist_in[g * a.sel_M + jj] : 0;
       }
       float s2 = 0.f, sx = 0.f, xn = 0.f;
-      static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
-        f32x16 o = z[ob];
-        if (a.add_c) o = o + load_block(cptr + ob * 32);
-        o = o + load_block(xhptr + ob * 32);
-        const f32x16 xb = load_block(xptr + ob * 32);
+      {
+        static_for<NDB>([&]<int ob>() QINCO_LAMBDA {
+          f32x16 o = z[ob];
+          if (a.add_c) o = o + load_block(cptr + ob * 32);
+          o = o + load_block(xhptr + ob * 32);
+          const f32x16 xb = load_block(xptr + ob * 32);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {   // (the order of the generic epilogue below: the same distances to the bit)
-          s2 = fmaf(o[i], o[i], s2);
-          sx = fmaf(o[i], xb[i], sx);
-          xn = fmaf(xb[i], xb[i], xn);
-        }
-        z[ob] = o;
-      });
+          for (int i = 0; i < 16; ++i) {   // (the order of the generic epilogue below: the same distances to the bit)
+            s2 = fmaf(o[i], o[i], s2);
+            sx = fmaf(o[i], xb[i], sx);
+            xn = fmaf(xb[i], xb[i], xn);
+          }
+          z[ob] = o;
+        });
+      }
       s2 += __shfl_xor(s2, 32);
       sx += __shfl_xor(sx, 32);
       xn += __shfl_xor(xn, 32);
@@ -650,8 +655,8 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
       // (select.hpp: sel_key, ties -> lower index) -- is the number of keys below its own: C / 2 LDS reads per lane, all rows at once,
       // no serial chain at the end of the workgroup's life (a one-wave wave_top_t here cost 6 % of a qinco2-S encode).  Ranks are a
       // permutation of 0 .. C-1: rank < T = winner, and the rank is its place in the next beam.
-      __shared__ unsigned long long sel_keys[128];
-      __shared__ int sel_idx[128];
+      unsigned long long* const sel_keys = reinterpret_cast<unsigned long long*>(lds_ring + RING4);   // [128]
+      int* const sel_idx = reinterpret_cast<int*>(lds_ring + RING4 + 64);                              // [128]
       auto lds_barrier = [&]() QINCO_LAMBDA {   // (raw: __syncthreads would also wait for the ring's tail DMAs)
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)

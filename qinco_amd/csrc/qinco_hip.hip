@@ -151,7 +151,8 @@ struct qinco_handle_s {
   // through HBM.  When the shape has an un-folded instance, decode uses it with its own (complete) weight stream.
   const MlpInstance* dec_inst = nullptr;
   StreamDims dec_sd{};
-  // opt-in (QINCO_CREATE_EPILOGUE_SELECT): the encode instance with the per-vector top-T in its epilogue (VAR bit 2048, same weight stream)
+  // the encode instance with the per-vector top-T in its epilogue (VAR bit 2048): the KHEAD + SELEP form by default where the shape has it,
+  // the twin's on request (QINCO_CREATE_EPILOGUE_SELECT)
   const MlpInstance* sel_inst = nullptr;
   // production instance with KHEAD (VAR bit 4096): its twin without, for launches whose groups the KHEAD kernel does not take (a wave's
   // 32 rows must span at most two groups: A >= 32 or A == 16) and for the epilogue-selection instance; alt_wstream = the same weights
@@ -250,7 +251,7 @@ static double mlp_flops_per_row(const qinco_handle_s* h) {
 //   FOLD:   R x (4 L De Dh + [De != D] 2 De D)  +  G x 2 D De                       (U = W_x xhat once per group);
 //   FOLD2:  R x ((4 L - 2) De Dh + [De != D] 2 De D)  +  G x (2 D De + 2 De Dh)     (Q = W_up[0] U too);
 //   decode in one launch of the small form: every row is its own group, U and Q are computed per row.
-static double mlp_flops_executed(const qinco_handle_s* h, double R, double G, bool folded, bool fold2, bool khead = false) {
+static double mlp_flops_executed(const qinco_handle_s* h, double R, double G, bool folded, bool fold2, bool khead = false, bool khead_epilogue = false) {
   const qinco_desc& d = h->user;
   const double L = h->d.L;   // (a model without FFN blocks runs one all-zero block)
   if (!folded) return R * (2.0 * (d.De + d.D) * d.De + 4.0 * L * d.De * d.Dh + (d.De != d.D ? 4.0 * d.D * d.De : 0.0));
@@ -268,7 +269,7 @@ static double mlp_flops_executed(const qinco_handle_s* h, double R, double G, bo
     if (rows_per_group < 32 && ((int)rows_per_group == 0 || 32 % (int)rows_per_group != 0)) ng += 1;
     per_row += 4.0 * (h->d.De + h->d.Dh) * ((ng + 1) / 2);
     // ... and, without projections, its epilogue adds xhat and lays x out the same way: 2 x one MFMA per block (encode: x is given)
-    if (h->d.De == h->d.D) per_row += 8.0 * h->d.D;
+    if (khead_epilogue && h->d.De == h->d.D) per_row += 8.0 * h->d.D;   // (not with the selection in the epilogue: that one gathers its rows)
   }
   return R * per_row + G * per_group;
 }
@@ -911,7 +912,7 @@ struct CreateOpts {
 };
 static const int kCreateFlagMask = QINCO_CREATE_SPLIT_F16 | QINCO_CREATE_IVF_FP32 | QINCO_CREATE_TABLE_VALU | QINCO_CREATE_DECODE_FOLDED |
                                    QINCO_CREATE_TABLE_NO_COOP | QINCO_CREATE_SPLIT_NO_CALIBRATION | QINCO_CREATE_NO_PRESEL_FUSION |
-                                   QINCO_CREATE_NO_SMALL_LAUNCH | QINCO_CREATE_EPILOGUE_SELECT;
+                                   QINCO_CREATE_NO_SMALL_LAUNCH | QINCO_CREATE_EPILOGUE_SELECT | QINCO_CREATE_NO_EPILOGUE_SELECT;
 
 static void env_opts(CreateOpts& o) {
 #ifdef QINCO_EXPERIMENT
@@ -1081,10 +1082,18 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
     }
     h->alt_inst = ai;
   }
-  if (fn && (create_flags & QINCO_CREATE_EPILOGUE_SELECT) && !(fn->var & 2048) && d.De == d.D && want_var < 0) {
+  if (fn && !(create_flags & QINCO_CREATE_NO_EPILOGUE_SELECT) && !(fn->var & 2048) && d.De == d.D && want_var < 0) {
+    // the step's top-T in the fused-MLP kernel's epilogue: by default with the instance's own KHEAD + SELEP form (it reads the production
+    // stream), on request (QINCO_CREATE_EPILOGUE_SELECT) also with the twin's SELEP form (measured no faster than the two kernels)
     const int base = fn->var & ~4096;
-    const MlpInstance* si = find_mlp_instance(d.D, d.De, d.Dh, fn->P, base | 2048);
-    if (si && si->P == fn->P && si->var == (base | 2048)) h->sel_inst = si;
+    if (fn->var & 4096) {
+      const MlpInstance* si = find_mlp_instance(d.D, d.De, d.Dh, fn->P, fn->var | 2048);
+      if (si && si->P == fn->P && si->var == (fn->var | 2048)) h->sel_inst = si;
+    }
+    if (!h->sel_inst && (create_flags & QINCO_CREATE_EPILOGUE_SELECT)) {
+      const MlpInstance* si = find_mlp_instance(d.D, d.De, d.Dh, fn->P, base | 2048);
+      if (si && si->P == fn->P && si->var == (base | 2048)) h->sel_inst = si;
+    }
   }
   int rc = 0;
   auto bail = [&](int code) {
@@ -1530,9 +1539,23 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
   if (nt > 0 || !h->sel_inst || decode) a.sel_T = 0;   // (the epilogue selection lives in the 128-row encode kernel)
   // the 128-row instance this launch takes; KHEAD only for groups of A >= 32 or A == 16 rows (a wave's 32 rows span at most two)
   const MlpInstance* ran = unfolded ? h->dec_inst : (a.sel_T > 0 ? h->sel_inst : h->inst);
-  if (!unfolded && h->alt_inst && (a.sel_T > 0 || !(a.A >= 32 || a.A == 16))) {
-    if (a.sel_T == 0) ran = h->alt_inst;
-    a.wstream = h->alt_wstream[m];
+  if (!unfolded && h->alt_inst) {
+    const bool khead_ok = a.A >= 32 || a.A == 16;
+    if (a.sel_T > 0) {
+      if (h->sel_inst->var & 4096) {       // KHEAD + SELEP: only for the groups KHEAD takes, else the plain two-kernel form on the twin
+        if (!khead_ok) {
+          a.sel_T = 0;
+          if (did_select) *did_select = false;
+          ran = h->alt_inst;
+          a.wstream = h->alt_wstream[m];
+        }
+      } else {
+        a.wstream = h->alt_wstream[m];     // (the twin's SELEP instance reads the ob-outer stream)
+      }
+    } else if (!khead_ok) {
+      ran = h->alt_inst;
+      a.wstream = h->alt_wstream[m];
+    }
   }
   if (did_select) *did_select = a.sel_T > 0;
   if (nt > 0) {   // small launch: workgroups of 16 nt rows, same head (T + U, relu(P + Q)) and the same products in the same order
@@ -1561,7 +1584,7 @@ static int launch_mlp(qinco_handle_s* h, MlpArgs a, int m, hipStream_t st, bool 
     HIP_TRY(hipEventRecord(e1, st));
     h->prof_flops += (double)a.R * mlp_flops_per_row(h);
     h->prof_flops_exec += mlp_flops_executed(h, (double)a.R, (double)(a.R / a.A), h->fold && !unfolded, h->fold2 && !unfolded,
-                                             nt == 0 && (ran->var & 4096));
+                                             nt == 0 && (ran->var & 4096), nt == 0 && (ran->var & 4096) && a.sel_T == 0);
   }
   return 0;
 }

@@ -29,7 +29,7 @@ class QincoEngine:
         """split_f16: opt-in split-fp16 evaluation of the FFN blocks (include/qinco_hip.h, QINCO_CREATE_SPLIT_F16): several
         times the fp32-MFMA throughput, fp32-class accuracy but not the fp32 path's bits.
         diagnostics: qinco_options knobs for A/B runs and the race-detector tests -- ivf_fp32, table_valu, decode_folded,
-        table_no_coop, split_no_calibration, no_presel_fusion, no_small_launch, epilogue_select (bools), mlp_variant=(P, VAR) (a non-production kernel instance of
+        table_no_coop, split_no_calibration, no_presel_fusion, no_small_launch, epilogue_select, no_epilogue_select (bools), mlp_variant=(P, VAR) (a non-production kernel instance of
         csrc/shapes.def), table_coop_max."""
         self.lib = _lib.load()
         self.cfg = cfg
@@ -40,7 +40,7 @@ class QincoEngine:
                          ("decode_folded", _lib.CREATE_DECODE_FOLDED), ("table_no_coop", _lib.CREATE_TABLE_NO_COOP),
                          ("split_no_calibration", _lib.CREATE_SPLIT_NO_CALIBRATION),
                          ("no_presel_fusion", _lib.CREATE_NO_PRESEL_FUSION), ("no_small_launch", _lib.CREATE_NO_SMALL_LAUNCH),
-                         ("epilogue_select", _lib.CREATE_EPILOGUE_SELECT)):
+                         ("epilogue_select", _lib.CREATE_EPILOGUE_SELECT), ("no_epilogue_select", _lib.CREATE_NO_EPILOGUE_SELECT)):
             if diag.pop(key, False):
                 flags |= bit
         P, var = diag.pop("mlp_variant", None) or (-1, -1)

@@ -6,7 +6,7 @@ from qinco_amd.config import BASELINE_CONFIGS
 cfg = BASELINE_CONFIGS["S"]
 sd = synth_state_dict(cfg, 1236)
 x = torch.from_numpy(synth_vectors(cfg, sd, 16384 * 3, seed=7)).cuda()
-for name, diag in (("selep", {"epilogue_select": True}), ("two_kernels", {})):
+for name, diag in (("selep", {"epilogue_select": True}), ("two_kernels", {"no_epilogue_select": True})):
     for mb in (16384, 1024):
         eng = QincoEngine(cfg, sd, max_batch=mb, diagnostics=diag)
         eng.encode(x[:mb], code_dtype=np.uint8); torch.cuda.synchronize()

@@ -12,7 +12,7 @@ for wl in wls:
     sd = synth_state_dict(cfg, 1236)
     n = 16384
     reps = 12 if wl in ("S", "IVF_S", "S_d96") else 3
-    eng = QincoEngine(cfg, sd, max_batch=n)
+    eng = QincoEngine(cfg, sd, max_batch=n)     # (the default: KHEAD, and the selection in its epilogue where the shape has that instance)
     assert "var=4476" in eng.describe(), eng.describe()
     twin = QincoEngine(cfg, sd, max_batch=n, diagnostics={"mlp_variant": (48, 380)})
     bad = rows = 0

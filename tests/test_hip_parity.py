@@ -464,7 +464,7 @@ def test_small_launch_form_is_bit_identical_to_the_128_row_kernels(shape):
 @pytest.mark.parametrize("shape,A,B", [("qinco2-S", 16, 8), ("qinco2-S", 16, 4), ("qinco2-S", 16, 2), ("qinco2-S", 8, 16), ("qinco2-S", 32, 4),
                                        ("tiny_id", 8, 4), ("tiny_id", 8, 16), ("tiny_id", 4, 8), ("tiny_id", 16, 1)])
 def test_epilogue_selection_is_bit_identical_to_beam_select(shape, A, B):
-    """Opt-in (epilogue_select; measured slower than the write-back it saves): identity-projection models whose F * A
+    """(Default where the shape has the KHEAD + SELEP instance, opt-in `epilogue_select` elsewhere): identity-projection models whose F * A
     candidates per vector fit a 128-row workgroup take the step's top-B inside the fused-MLP kernel's epilogue (csrc/mlp_kernel.hpp
     SELEP): no candidate / distance write-back, no beam_select launch.  Same distances, the same (distance, index) order as
     beam_select_kernel: codes and tracked reconstructions must equal the two-kernel form bit for bit -- at sizes where the last workgroup is partly empty, with heavy ties (duplicated vectors), and with the beam still
@@ -478,7 +478,7 @@ def test_epilogue_selection_is_bit_identical_to_beam_select(shape, A, B):
     x[100:200] = x[0:100]            # duplicated rows: identical candidate distances
     xd = torch.from_numpy(x).cuda()
     fused = QincoEngine(cfg, sd, max_batch=20000, diagnostics={"epilogue_select": True})
-    plain = QincoEngine(cfg, sd, max_batch=20000)
+    plain = QincoEngine(cfg, sd, max_batch=20000, diagnostics={"no_epilogue_select": True})
     for n in (20000, 4097, 2049):      # (large enough for the 128-row kernels: below, the small-launch form serves the step)
         cf, hf = fused.encode(xd[:n], return_xhat=True)
         cp, hp = plain.encode(xd[:n], return_xhat=True)
@@ -506,7 +506,7 @@ def test_khead_instance_is_bit_identical_to_its_twin(model, A, B, D):
     x = synth_vectors(cfg, sd, n, seed=44)
     x[100:200] = x[0:100]
     xd = torch.from_numpy(x).cuda()
-    khead = QincoEngine(cfg, sd, max_batch=n)
+    khead = QincoEngine(cfg, sd, max_batch=n, diagnostics={"no_epilogue_select": B % 2 == 0})   # (B = 1: the default, selection in the epilogue where eligible)
     assert "var=4476" in khead.describe(), khead.describe()
     twin = QincoEngine(cfg, sd, max_batch=n, diagnostics={"mlp_variant": (48, 380)})
     for m in (n, n // 2 + 1, 4097):

@@ -10,8 +10,13 @@ rank per GPU (like the reference's `accelerate launch --multi_gpu`, run.sh:8).
 
 A "step" = one pass of the hot path (model(x, step="encode")) over one batch of `--batch` synthetic fp32 vectors per
 GPU.  Every step (and every warm-up step) encodes a DIFFERENT batch; all batches are generated on the device before the
-timed region (inputs resident in HBM).  Sharding is the reference's (contiguous ranges, search_tasks.py:103-104), no
-data-path collective; the uint8 codes of all timed steps are gathered to rank 0 over RCCL inside the timed region.
+timed region (inputs resident in HBM).  The timed region is the PRODUCT's database encode at every N: the rank's contiguous range
+(search_tasks.py:103-104) goes through qinco_amd.encode_db.encode_shard -- QINCoHIP model calls in passes of `--batch` rows, codes
+narrowed to bytes and copied to the host under the next pass -- and, for N > 1, through encode_db.gather_codes: no data-path
+collective, one send of the byte shard per rank > 0, rank 0 receives each into its rows of one (N, M) matrix (RCCL; inside the
+timed region).  multi_gpu.per_rank says, per rank: GPU index, PCI bus id, NUMA node, encode s, gather s, bytes, the ranks the
+payload group saw, and whether the rows that arrived on rank 0 are the shard's (a position-weighted checksum).
+`--dry-rccl` runs only the communication steps on fake rows (seconds: first contact with a multi-GPU node).
   --scaling weak   (default, the driver's form): every rank encodes K batches of its own -> work grows with N;
   --scaling strong: ONE database of K x batch vectors (or --db N) is split over the ranks like encode_database does
                     (the north_star's "1B-vector encode" statement); a step is then 1/K of the whole job.
@@ -159,6 +164,156 @@ def call_with_timeout(fn, seconds):
     if "error" in box:
         raise box["error"]
     return box.get("value")
+
+
+def shard_checksum(codes: np.ndarray, first_row: int) -> int:
+    """Position-weighted 64-bit sum of a block of code rows (row index in the DATABASE, so a shard that lands in the wrong rows of
+    the gathered matrix -- or in the right rows in the wrong order -- changes it)."""
+    total = np.uint64(0)
+    if codes.size == 0:
+        return 0
+    cols = (np.arange(codes.shape[1], dtype=np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F) + np.uint64(1))[None, :]
+    with np.errstate(over="ignore"):
+        for i0 in range(0, len(codes), 1 << 20):           # (blocks: the uint64 temporaries of 10^8 rows would be gigabytes)
+            blk = codes[i0:i0 + (1 << 20)]
+            rows = (np.arange(first_row + i0, first_row + i0 + len(blk), dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1))[:, None]
+            total = total + ((blk.astype(np.uint64) + np.uint64(1)) * rows * cols).sum(dtype=np.uint64)
+    return int(total)
+
+
+def fake_code_rows(first_row: int, rows: int, M: int) -> np.ndarray:
+    """Deterministic byte codes of database rows [first_row, first_row + rows): every rank can make its shard and rank 0 the whole
+    matrix it must receive (--dry-rccl)."""
+    r = np.arange(first_row, first_row + rows, dtype=np.uint64)[:, None]
+    c = np.arange(M, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        return (((r * np.uint64(2654435761) + c * np.uint64(40503)) >> np.uint64(7)) & np.uint64(255)).astype(np.uint8)
+
+
+def dry_rccl(torch, dist, args, rank, world, dev, dev_index, data_group, data_note, affinity, wedged, json_fd):
+    """--dry-rccl: first contact with a multi-GPU node without a model in the way.  Per rank, each step under --rccl-timeout and
+    each recorded with its seconds or its error:
+      1. communicator: the payload group was created (and probed with one all-reduce) in main() -- RCCL with --backend nccl;
+      2. p2p: one grouped exchange of 1 byte with EVERY peer (batch_isend_irecv: the ncclGroupStart / ncclSend / ncclRecv /
+         ncclGroupEnd shape of qinco_gather_codes and of gather_codes' transfers);
+      3. gather_codes: the product's end-of-job gather (qinco_amd.encode_db) of --dry-rows fake byte rows x 8 codes, sharded like
+         encode_database shards (the last rank takes the remainder); rank 0 compares every received row with what it must be;
+      4. native: RcclComm.from_process_group (ncclCommInitRank through ctypes, the id broadcast on the control plane), ncclCommCount,
+         and qinco_gather_codes (include/qinco_hip.h) on the same rows -- only with --backend nccl (it needs one GPU per rank).
+    Rank 0 prints one JSON line; exit status 0 even when steps failed (the line says which)."""
+    from qinco_amd.affinity import gpu_pci_address
+    from qinco_amd.encode_db import gather_codes, shard_bounds
+    M = 8
+    N = args.dry_rows
+    start, end = shard_bounds(N, world, rank)
+    mine_np = fake_code_rows(start, end - start, M)
+    steps = {}
+    use_rccl = data_group is not None
+    pdev = dev if use_rccl else torch.device("cpu")
+
+    def step(name, fn):
+        nonlocal wedged
+        t0 = time.perf_counter()
+        try:
+            if wedged:
+                raise RuntimeError("skipped: an earlier RCCL call on this rank never returned")
+            val = call_with_timeout(fn, args.rccl_timeout)
+            steps[name] = {"ok": True, "s": time.perf_counter() - t0, **(val or {})}
+        except BaseException as e:                            # noqa: BLE001
+            wedged = wedged or isinstance(e, TimeoutError)
+            steps[name] = {"ok": False, "s": time.perf_counter() - t0, "error": f"{type(e).__name__}: {e}"[:300]}
+
+    steps["communicator"] = {"ok": use_rccl or args.backend == "gloo", "backend": "rccl" if use_rccl else ("gloo" if args.backend == "gloo" else None),
+                             "error": data_note, "ranks": int(dist.get_world_size(data_group)) if use_rccl else int(dist.get_world_size()) if world > 1 else 1}
+
+    def set_device():
+        if torch.cuda.is_available():
+            torch.cuda.set_device(dev_index)
+
+    def p2p():
+        if world == 1:
+            return {"peers": 0}
+        set_device()
+        send = torch.full((1,), rank, dtype=torch.uint8, device=pdev)
+        recv = [torch.full((1,), 255, dtype=torch.uint8, device=pdev) for _ in range(world)]
+        ops = []
+        for peer in range(world):
+            if peer != rank:
+                ops.append(dist.P2POp(dist.isend, send, peer, group=data_group))
+                ops.append(dist.P2POp(dist.irecv, recv[peer], peer, group=data_group))
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+        if use_rccl:
+            torch.cuda.synchronize(dev)
+        got = [int(recv[p].item()) for p in range(world) if p != rank]
+        if got != [p for p in range(world) if p != rank]:
+            raise RuntimeError(f"wrong bytes from the peers: {got}")
+        return {"peers": len(got)}
+
+    gst: dict = {}
+
+    def gather():
+        set_device()
+        full = gather_codes(mine_np, N, dist, device=dev if use_rccl else None, code_dtype="compact", group=data_group, stats=gst)
+        if rank == 0:
+            if full.shape != (N, M) or not np.array_equal(full, fake_code_rows(0, N, M)):
+                raise RuntimeError("the gathered matrix is not the database's codes")
+        return {k: gst.get(k) for k in ("ranks", "wire_dtype", "bytes_sent", "bytes_received", "transport", "buffers")} | {"transfer_s": gst.get("seconds")}
+
+    def native():
+        from qinco_amd.comm import RcclComm, gather_codes_native
+        torch.cuda.set_device(dev_index)
+        comm = RcclComm.from_process_group()                  # the id travels on the gloo control plane
+        seen = comm.count()
+        counts = [shard_bounds(N, world, r)[1] - shard_bounds(N, world, r)[0] for r in range(world)]
+        out = gather_codes_native(torch.from_numpy(mine_np).to(dev), counts, rank, root=0, comm=comm)
+        ok = True
+        if rank == 0:
+            ok = bool(np.array_equal(out.cpu().numpy(), fake_code_rows(0, N, M)))
+        comm.close()
+        if not ok:
+            raise RuntimeError("qinco_gather_codes: the gathered matrix is not the database's codes")
+        return {"nccl_comm_count": seen}
+
+    if world > 1 and (use_rccl or args.backend == "gloo"):
+        step("p2p_1_byte_with_every_peer", p2p)
+        step("gather_codes", gather)
+        if use_rccl:
+            step("native_qinco_gather_codes", native)
+    me = {"rank": rank, "gpu": dev_index, "pci_bus_id": gpu_pci_address(dev_index), "numa_node": (affinity or {}).get("numa_node"),
+          "rows": end - start, "steps": steps}
+    allr = [me]
+    if world > 1:
+        allr = [None] * world
+        dist.all_gather_object(allr, me)                      # gloo control plane
+    if rank == 0:
+        names = [k for k in steps]
+        out = {"metric": "dry-rccl: communicator + 1-byte grouped send/recv per peer + gather_codes of fake rows", "n_gpus": world,
+               "backend": args.backend, "rows": N, "codes_per_row": M,
+               "all_ok": all(r["steps"][k]["ok"] for r in allr for k in r["steps"]),
+               "steps_ok_on_all_ranks": {k: all(r["steps"].get(k, {}).get("ok", False) for r in allr) for k in names},
+               "rccl_ranks_seen": steps.get("gather_codes", {}).get("ranks"),
+               "nccl_comm_count": steps.get("native_qinco_gather_codes", {}).get("nccl_comm_count"),
+               "per_rank": allr}
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1:
+        dist.barrier()
+    if wedged:
+        sys.stderr.flush()
+        os._exit(0)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def dry_rccl_on_gloo_without_gpu(torch, dist, args, rank, world, json_fd):
+    """`--dry-rccl --backend gloo` on a machine without a GPU: the same steps over host buffers (the CPU test tier runs them at 2, 3
+    and 8 ranks)."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dry_rccl(torch, dist, args, rank, world, torch.device("cpu"), 0, None, None, None, False, json_fd)
 
 
 def synth_batch_device(torch, cfg, mean_t, std, n, seed, dev):
@@ -419,6 +574,13 @@ def main():
                     help="seconds an RCCL call (communicator creation, the gather) may take before the run falls back to part files")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="payload gather: nccl = RCCL over xGMI (one GPU per rank). gloo is a test hook: ranks may share a GPU.")
+    ap.add_argument("--dry-rccl", action="store_true",
+                    help="no model, no encode: build the communicator(s), one 1-byte grouped send / recv with every peer, then the product's "
+                         "gather_codes (and the C-ABI qinco_gather_codes) on --dry-rows fake code rows, each step under --rccl-timeout; "
+                         "prints one JSON line saying which steps worked on which rank (first contact with a multi-GPU node in seconds)")
+    ap.add_argument("--dry-rows", type=int, default=1_000_000, help="--dry-rccl: rows of the fake database")
+    ap.add_argument("--c1-cpu-vectors", type=int, default=256,
+                    help="vectors of the c1 leg's CPU sample (BASELINE.md 3 / SURVEY 8d quote C1's CPU protocol at 10 000: minutes of host time)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -439,6 +601,9 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run `python bench.py --gpus N` bare)")
     ndev = torch.cuda.device_count()
+    cpu_dry = ndev == 0 and args.dry_rccl and args.backend == "gloo"    # (the communication steps alone, host buffers: runs anywhere)
+    if cpu_dry:
+        return dry_rccl_on_gloo_without_gpu(torch, dist, args, rank, world, json_fd)
     if ndev == 0:
         raise SystemExit("bench.py needs a GPU (qinco_amd has no CPU path)")
     if args.backend == "nccl" and world > ndev and not os.environ.get("QINCO_BENCH_NCCL_SHARED_GPU"):   # (test hook: let RCCL refuse it)
@@ -477,20 +642,26 @@ def main():
                 data_group = None
                 data_note = data_note or "RCCL unavailable on another rank"
 
+    if args.dry_rccl:
+        return dry_rccl(torch, dist, args, rank, world, dev, dev_index, data_group, data_note, affinity, wedged, json_fd)
+
     from qinco_amd import QincoEngine, synth_state_dict
     from qinco_amd.config import BASELINE_CONFIGS
-    from qinco_amd.encode_db import shard_bounds
+    from qinco_amd.encode_db import compact_code_dtype, encode_shard, gather_codes, shard_bounds
     from qinco_amd.evaluate import sqerr_sum
+    from qinco_amd.model import QINCoHIP
 
     cfg = BASELINE_CONFIGS[args.workload]
     sd = synth_state_dict(cfg, 1236)
-    eng = QincoEngine(cfg, sd, max_batch=args.batch, split_f16=args.split_f16)
+    # the reference-shaped model object (model(x, step="encode") -> (M, n) int64 on x's device): what encode_database drives
+    model = QINCoHIP(cfg, sd, max_batch=args.batch, device=dev_index, split_f16=args.split_f16)
+    eng = model.engine
     K, W = args.steps, args.warmup
     strong = args.scaling == "strong"
 
-    # The synthetic database.  weak: step s of rank r encodes batch (r (W + K) + s) of one seeded stream.  strong: the database
-    # is batches 0 .. ceil(db / batch) - 1 of that stream; rank r owns the reference's contiguous range of it
-    # (search_tasks.py:103-104) and encodes it in passes of `batch` rows.  Everything is resident in HBM before the clock starts.
+    # The synthetic database.  weak: rank r owns batches r K .. r K + K - 1 of one seeded stream -- the reference's contiguous range
+    # (search_tasks.py:103-104) of a database of world x K x batch rows.  strong: the database is batches 0 .. ceil(db / batch) - 1
+    # of that stream and rank r owns its range of it.  The rank's whole shard is ONE tensor resident in HBM before the clock starts.
     mean_t = torch.from_numpy(np.asarray(sd["data_mean"])).to(dev)
     std = float(sd["data_std"])
 
@@ -502,14 +673,15 @@ def main():
         db_size = args.db or K * args.batch
         start, end = shard_bounds(db_size, world, rank)
         b0, b1 = start // args.batch, (end + args.batch - 1) // args.batch
-        rows = torch.cat([stream_batch(i) for i in range(b0, b1)])[start - b0 * args.batch: end - b0 * args.batch] \
+        shard = torch.cat([stream_batch(i) for i in range(b0, b1)])[start - b0 * args.batch: end - b0 * args.batch].contiguous() \
             if end > start else torch.empty((0, cfg.D), device=dev)
-        batches = [rows[i:i + args.batch] for i in range(0, len(rows), args.batch)]
-        my_vecs = end - start
     else:
         db_size = K * args.batch * world
-        batches = [stream_batch(rank * K + s) for s in range(K)]
-        my_vecs = K * args.batch
+        start, end = shard_bounds(db_size, world, rank)
+        shard = torch.cat([stream_batch(rank * K + s) for s in range(K)]) if K else torch.empty((0, cfg.D), device=dev)
+    my_vecs = end - start
+    assert len(shard) == my_vecs
+    batches = [shard[i:i + args.batch] for i in range(0, len(shard), args.batch)]     # (views: the extras' legs re-use them)
 
     def device_sync():        # (a wedged RCCL kernel would make a device-wide synchronize wait forever: the compute stream only)
         if wedged:
@@ -524,25 +696,28 @@ def main():
         device_sync()
 
     for xb in warm:
-        eng.encode(xb, code_dtype=np.int32 if cfg.ivf else np.uint8)
+        model(xb, step="encode")
     barrier()
     eng.profile_enable(True)
     eng.profile_read()
     barrier()
     t0 = time.perf_counter()
-    wire_np = np.int32 if cfg.ivf else np.uint8          # (an IVF id does not fit a byte)
-    wire_t = torch.int32 if cfg.ivf else torch.uint8
-    codes_steps = [eng.encode(xb, code_dtype=wire_np) for xb in batches]
-    mine = torch.cat(codes_steps) if codes_steps else torch.empty((0, cfg.M_total), dtype=wire_t, device=dev)
+    # ---- the timed region IS the product's database encode (qinco_amd.encode_db, search_tasks.py:85-137 minus the files):
+    # encode_shard over the rank's range in passes of `batch` rows (the model call asynchronous on this thread's stream, the codes
+    # of the previous pass narrowed to bytes and copied to the host on a helper thread), then gather_codes: every rank > 0 sends its
+    # (n_r, M) byte shard once, rank 0 receives each straight into its rows of ONE (N, M) matrix.
+    wire_np = compact_code_dtype(cfg.K, cfg.M_total, cfg.M)          # uint8; int32 with an IVF column (an IVF id does not fit a byte)
+    mine_np = encode_shard(model, shard, 0, my_vecs, batch=args.batch, code_dtype="compact", K=cfg.K, M=cfg.M)
+    if mine_np.size == 0:
+        mine_np = np.zeros((0, cfg.M_total), wire_np)
+    assert mine_np.shape == (my_vecs, cfg.M_total) and mine_np.dtype == wire_np
     t_enc = t_gather = 0.0
     gather_how = None
-    if world > 1:  # the end-of-job gather of the uint8 codes: one collective, shards padded to the longest
+    gstats: dict = {}
+    gathered = None
+    if world > 1:
         torch.cuda.synchronize(dev)
         t_enc = time.perf_counter() - t0
-        longest = max(shard_bounds(db_size, world, r)[1] - shard_bounds(db_size, world, r)[0] for r in range(world)) if strong \
-            else K * args.batch
-        pad = torch.zeros((longest, cfg.M_total), dtype=wire_t, device=dev)
-        pad[: len(mine)] = mine
         try:
             hook = os.environ.get("QINCO_BENCH_FORCE_GATHER_ERROR")   # test hook (tests/test_multi_gpu.py): the fail-soft paths
             if hook == "hang":
@@ -550,44 +725,51 @@ def main():
             elif hook:
                 raise RuntimeError("forced by QINCO_BENCH_FORCE_GATHER_ERROR")
             if data_group is not None:
-                bucket = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-
                 def gather_rccl():
                     torch.cuda.set_device(dev_index)
-                    dist.gather(pad, bucket, dst=0, group=data_group)
-                    torch.cuda.synchronize(dev)
-                call_with_timeout(gather_rccl, args.rccl_timeout)
+                    return gather_codes(mine_np, db_size, dist, device=dev, code_dtype="compact", group=data_group, stats=gstats)
+                gathered = call_with_timeout(gather_rccl, args.rccl_timeout)
                 gather_how = "rccl"
             elif args.backend == "gloo":
-                pad_c = pad.cpu()
-                bucket = [torch.empty_like(pad_c) for _ in range(world)] if rank == 0 else None
-                dist.gather(pad_c, bucket, dst=0)
+                gathered = gather_codes(mine_np, db_size, dist, code_dtype="compact", stats=gstats)
                 gather_how = "gloo (test hook: host buffers)"
             else:
                 raise RuntimeError(data_note or "no RCCL group")
             if rank == 0:
-                assert len(bucket) == world and all(b.shape == pad.shape for b in bucket)
+                assert gathered.shape == (db_size, cfg.M_total) and gathered.dtype == wire_np
         except BaseException as e:                            # noqa: BLE001 -- fail soft: the reference's own part files
             wedged = wedged or isinstance(e, TimeoutError)
             outdir = os.environ.get("QINCO_BENCH_PARTS", tempfile.gettempdir())
-            np.savez_compressed(os.path.join(outdir, f"qinco_bench_codes.part_{rank}.npz"), codes=mine.cpu().numpy())
+            np.savez_compressed(os.path.join(outdir, f"qinco_bench_codes.part_{rank}.npz"), codes=mine_np)
             gather_how = f"failed: {type(e).__name__}: {e}"[:300] + " -> part files"
+            gathered = None
         t_gather = time.perf_counter() - t0 - t_enc
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(False)
+    mine = torch.from_numpy(mine_np).to(dev)                  # (the extras decode / compare these codes on the device)
 
     per_rank = None
-    if world > 1:   # timing exchange on the control plane (gloo, host tensors)
+    if world > 1:   # timing and identity exchange on the control plane (gloo, host objects) -- after the clock has stopped
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        mine_t = torch.tensor([t_enc, t_gather, float(my_vecs), 0.0 if (gather_how or "").startswith("failed") else 1.0],
-                              dtype=torch.float64)
-        allt = [torch.empty_like(mine_t) for _ in range(world)]
-        dist.all_gather(allt, mine_t)
-        per_rank = [[float(v) for v in a] for a in allt]
+        from qinco_amd.affinity import gpu_pci_address
+        me = {"rank": rank, "gpu": dev_index, "pci_bus_id": gpu_pci_address(dev_index), "numa_node": (affinity or {}).get("numa_node"),
+              "vectors": int(my_vecs), "encode_s": t_enc, "gather_s": t_gather,
+              "gather_ok": not (gather_how or "").startswith("failed"), "gather": gather_how,
+              "bytes_sent": gstats.get("bytes_sent"), "bytes_received": gstats.get("bytes_received"),
+              "ranks_seen_by_payload_group": gstats.get("ranks"), "wire_dtype": gstats.get("wire_dtype"),
+              "transport": gstats.get("transport"), "buffers": gstats.get("buffers"),
+              # 64-bit sum of the shard's code bytes, weighted by position: rank 0 recomputes it from the gathered matrix
+              "shard_checksum": shard_checksum(mine_np, start)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, me)
+        if rank == 0 and gathered is not None:
+            for r, info in enumerate(per_rank):
+                s_r, e_r = shard_bounds(db_size, world, r)
+                info["rows_on_rank0_equal_to_the_shard"] = shard_checksum(gathered[s_r:e_r], s_r) == info["shard_checksum"]
 
     if rank == 0:
         total_vecs = db_size
@@ -621,13 +803,19 @@ def main():
         if world > 1:
             out["multi_gpu"] = {
                 "backend": args.backend, "control_plane": "gloo", "gather": gather_how,
-                "gather_ok_on_all_ranks": all(t[3] == 1.0 for t in per_rank),
+                "path": "qinco_amd.encode_db.encode_shard + gather_codes (the product's encode_database path: one send per rank > 0, "
+                        "irecv straight into rank 0's (N, M) matrix; search_tasks.py:95-134)",
+                "gather_ok_on_all_ranks": all(t["gather_ok"] for t in per_rank),
+                "gathered_rows_verified_on_rank0": (all(t.get("rows_on_rank0_equal_to_the_shard", False) for t in per_rank)
+                                                    if gathered is not None else None),
                 "rccl_note": data_note,
-                "per_rank_vectors": [int(t[2]) for t in per_rank],
-                "per_rank_encode_vectors_per_s": [t[2] / t[0] if t[0] > 0 else 0.0 for t in per_rank],
-                "per_rank_encode_s": [t[0] for t in per_rank],
-                "per_rank_gather_s": [t[1] for t in per_rank],
-                "gather_bytes_per_rank": int(longest * cfg.M_total * (4 if cfg.ivf else 1)),
+                "rccl_ranks_seen": gstats.get("ranks") if gather_how == "rccl" else None,
+                "per_rank_vectors": [t["vectors"] for t in per_rank],
+                "per_rank_encode_vectors_per_s": [t["vectors"] / t["encode_s"] if t["encode_s"] > 0 else 0.0 for t in per_rank],
+                "per_rank_encode_s": [t["encode_s"] for t in per_rank],
+                "per_rank_gather_s": [t["gather_s"] for t in per_rank],
+                "gather_bytes_per_rank": int(max(t["vectors"] for t in per_rank) * cfg.M_total * wire_np.itemsize),
+                "per_rank": per_rank,
                 "note": "gather time of a rank includes waiting for the slowest rank's encode",
             }
         if world == 1 and not args.no_extras and K > 0 and not strong and not cfg.ivf:

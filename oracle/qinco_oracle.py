@@ -262,9 +262,11 @@ def mse(x: np.ndarray, xhat: np.ndarray, mse_scale: float = 1.0) -> float:
 
 
 # --------------------------------------------------------------------------------------------------
-# look-up decoders downstream of the path.  PARITY UNPINNED: the reference modules that hold them
-# (qinco/search/search_utils.py, qinco/search/pairwise_decoder.py) import faiss / torcheval, which are not installed
-# here, so no golden vectors could be produced by the reference itself; these restate the cited lines directly.
+# look-up decoders downstream of the path.  Pinned since round 5: tests/golden/lut_decoders.npz and the mid stage
+# of tests/golden/rerank_ivf.npz hold what the reference's own PairwiseDecoderIVF.forward / map_codes and
+# reconstruct_from_fixed_codebooks returned (tests/golden/make_golden.py imports qinco/search/{pairwise_decoder,search_utils}.py
+# with empty placeholder modules for the faiss / torcheval imports none of those lines uses);
+# tests/test_oracle_vs_golden.py::test_oracle_lookup_decoders_equal_the_reference checks these restatements bit for bit.
 # --------------------------------------------------------------------------------------------------
 def reconstruct_from_fixed_codebooks(codes: np.ndarray, codebooks: np.ndarray) -> np.ndarray:
     """search_utils.py:105-115."""

@@ -15,7 +15,9 @@ from . import _lib
 
 
 class NcclUniqueId(C.Structure):
-    _fields_ = [("internal", C.c_char * 128)]
+    # (c_ubyte, not c_char: ctypes hands a c_char array back as bytes CUT AT THE FIRST NUL -- an id is a socket address and a
+    # magic number, full of zero bytes; rounds 2-4 wrote such a truncated id to the file and no 2-GPU box ever ran it)
+    _fields_ = [("internal", C.c_ubyte * 128)]
 
 
 def _librccl() -> C.CDLL:
@@ -38,46 +40,96 @@ def _librccl() -> C.CDLL:
 
 
 class RcclComm:
-    """ncclCommInitRank over a unique id exchanged through `id_file` (rank 0 writes it, the others wait for it).  max_skew_s: how
-    much older than this rank's own start the file may be (ranks of one job start within seconds of each other)."""
+    """ncclCommInitRank over a unique id that reaches the ranks one of three ways:
 
-    def __init__(self, rank: int, world: int, id_file: str, timeout_s: float = 120.0, max_skew_s: float = 30.0):
+    * `uid` -- the 128 bytes themselves, for launchers with a channel of their own (`RcclComm.from_process_group`: rank 0's id
+      broadcast over an existing torch.distributed control plane, no file at all);
+    * `id_file` + `nonce` -- rank 0 writes `id || nonce` and the others accept only a file that ends in THEIR nonce (a job id, the
+      launcher's run id, a random token passed on the command line): a file left behind by an earlier job under the same path can
+      never be taken for this job's, however late a rank starts and whatever the clocks of the hosts / the file server say;
+    * `id_file` alone -- single-host fall-back: a file is fresh when it was written at most `timeout_s` before this rank started,
+      measured on this host's clock (the skew a late rank is allowed equals the time rank 0 is prepared to wait for it).
+
+    Rank 0 replaces the file atomically and removes it once every rank has joined (ncclCommInitRank is collective)."""
+
+    def __init__(self, rank: int, world: int, id_file: Optional[str] = None, timeout_s: float = 120.0, nonce: Optional[str] = None,
+                 uid: Optional[bytes] = None):
         _lib.load()                      # one HIP runtime first
         self.rccl = _librccl()
         self.rank, self.world = rank, world
+        if uid is None and id_file is None:
+            raise ValueError("RcclComm needs the unique id (uid=) or a file to exchange it through (id_file=)")
+        if uid is not None:
+            if len(uid) != 128:
+                raise ValueError("an RCCL unique id is 128 bytes")
+            uid_s = NcclUniqueId()
+            C.memmove(C.byref(uid_s), bytes(uid), 128)
+        else:
+            uid_s = self._exchange_through_file(rank, id_file, timeout_s, nonce)
+        self.comm = C.c_void_p()
+        self.rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
+        self._ok(self.rccl.ncclCommInitRank(C.byref(self.comm), world, uid_s, rank))
+        if rank == 0 and uid is None:               # every rank has joined: the id has served
+            try:
+                os.remove(id_file)
+            except OSError:
+                pass
+
+    def new_unique_id(self) -> bytes:
         uid = NcclUniqueId()
-        # The id file carries a start time next to the id: a file left behind by an EARLIER job (same path) is older than this
-        # process and is ignored by the waiting ranks -- they would otherwise hang in ncclCommInitRank on a dead id.  Rank 0
-        # replaces the file atomically and removes it once every rank has joined.
+        self._ok(self.rccl.ncclGetUniqueId(C.byref(uid)))
+        return bytes(uid.internal)
+
+    @classmethod
+    def from_process_group(cls, group=None) -> "RcclComm":
+        """The communicator of the ranks of an initialised torch.distributed group (any backend: gloo is the control plane of
+        qinco_amd.encode_db): rank 0's unique id travels in one broadcast_object_list, nothing touches the file system."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [None]
+        if rank == 0:
+            probe = cls.__new__(cls)
+            _lib.load()
+            probe.rccl = _librccl()
+            box[0] = probe.new_unique_id()
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, uid=box[0])
+
+    def count(self) -> int:
+        """ncclCommCount: the ranks RCCL itself sees in this communicator."""
+        n = C.c_int(0)
+        self.rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._ok(self.rccl.ncclCommCount(self.comm, C.byref(n)))
+        return n.value
+
+    def _exchange_through_file(self, rank: int, id_file: str, timeout_s: float, nonce: Optional[str]) -> NcclUniqueId:
+        uid = NcclUniqueId()
+        tag = nonce.encode() if nonce is not None else b""
         born = time.time()
         if rank == 0:
             self._ok(self.rccl.ncclGetUniqueId(C.byref(uid)))
             tmp = id_file + f".tmp{os.getpid()}"
             with open(tmp, "wb") as f:
-                f.write(bytes(uid.internal))
+                f.write(bytes(uid.internal) + tag)
             os.replace(tmp, id_file)
-        else:
-            t0 = time.time()
-            while True:
-                try:
-                    fresh = os.path.getmtime(id_file) >= born - max_skew_s
-                    blob = open(id_file, "rb").read() if fresh else b""
-                except OSError:
-                    blob = b""
-                if len(blob) == 128:
-                    break
-                if time.time() - t0 > timeout_s:
-                    raise TimeoutError(f"no fresh RCCL unique id at {id_file}")
-                time.sleep(0.05)
-            C.memmove(C.byref(uid), blob, 128)
-        self.comm = C.c_void_p()
-        self.rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
-        self._ok(self.rccl.ncclCommInitRank(C.byref(self.comm), world, uid, rank))
-        if rank == 0:               # every rank has joined (the call is collective): the id has served
+            return uid
+        t0 = time.time()
+        while True:
             try:
-                os.remove(id_file)
+                blob = open(id_file, "rb").read()
+                if nonce is not None:
+                    ok = len(blob) == 128 + len(tag) and blob[128:] == tag       # this job's file: no clock is consulted
+                else:
+                    ok = len(blob) == 128 and os.path.getmtime(id_file) >= born - timeout_s
             except OSError:
-                pass
+                ok = False
+            if ok:
+                break
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"no RCCL unique id of this job at {id_file}" + (f" (nonce {nonce!r})" if nonce is not None else ""))
+            time.sleep(0.05)
+        C.memmove(C.byref(uid), blob[:128], 128)
+        return uid
 
     def _ok(self, rc: int):
         if rc != 0:

@@ -14,7 +14,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // Bumped by hand whenever the MEANING of an argument block or of a launcher changes without changing its size (instance_abi).
-constexpr int kInstanceAbiVersion = 3;
+constexpr int kInstanceAbiVersion = 4;
+// Launchers a kernel-instance module hands over in qinco_instance_info's fns[] (mlp, xproj, table, IVF, small-launch form or null).
+// Part of instance_abi(): a module exporting another number of launchers is refused at load.
+constexpr int kInstanceNFns = 5;
 
 // Fragment (1 KiB = 64 lanes x float4) counts of each section of the packed per-step weight stream.
 // Every section is padded to a multiple of the ring depth P so ring slots are compile-time constants.
@@ -197,7 +200,8 @@ struct SmallArgs {
 
 // Source-version check between the library and a module built on demand: the sizes of the argument blocks they exchange.
 constexpr int instance_abi() {
-  return (int)((sizeof(MlpArgs) << 20) | (sizeof(XprojArgs) << 8) | sizeof(IvfArgs)) ^ (int)((sizeof(TableArgs) << 12) | (sizeof(SmallArgs) << 4)) ^ (kInstanceAbiVersion << 26);
+  return (int)((sizeof(MlpArgs) << 20) | (sizeof(XprojArgs) << 8) | sizeof(IvfArgs)) ^ (int)((sizeof(TableArgs) << 12) | (sizeof(SmallArgs) << 4)) ^
+         (int)(sizeof(SmallStep) << 17) ^ (kInstanceNFns << 23) ^ (kInstanceAbiVersion << 26);
 }
 static_assert(sizeof(MlpArgs) < 2048 && sizeof(XprojArgs) < 4096 && sizeof(IvfArgs) < 256, "instance_abi packing");
 

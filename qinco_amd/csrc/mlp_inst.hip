@@ -68,22 +68,28 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t qinco_module_table_l
 }
 // Built on demand as a shared object of its own (qinco_amd.build.ensure_instance) and registered with qinco_load_instance:
 // v = {D, De, Dh, P, VAR, 0}, fns = {mlp launcher, xproj launcher, table launcher (K = 256 pre-selection for this D), IVF coarse assignment for this D,
-// small-launch form or nullptr}; returns instance_abi() (the sizes of the argument blocks) as the
-// source-version check (a module built against another csrc/mlp_args.hpp must not be launched).
+// small-launch form or nullptr} -- kInstanceNFns entries, of which at most `cap` (the caller's array length) are written; returns
+// instance_abi() (the sizes of the argument blocks and the launcher count) as the source-version check (a module built against
+// another csrc/mlp_args.hpp must not be launched).
 extern "C" hipError_t QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)(const qinco::XprojArgs* a, hipStream_t stream);
-extern "C" __attribute__((visibility("default"))) int qinco_instance_info(int* v, void** fns) {
+extern "C" __attribute__((visibility("default"))) int qinco_instance_info(int* v, void** fns, int cap) {
   v[0] = QD;
   v[1] = QDE;
   v[2] = QDH;
   v[3] = QP;
   v[4] = QVAR;
-  fns[0] = reinterpret_cast<void*>(&QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR));
-  fns[1] = reinterpret_cast<void*>(&QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR));
-  fns[2] = reinterpret_cast<void*>(&qinco_module_table_launch);
-  fns[3] = reinterpret_cast<void*>(&qinco_module_ivf_launch);
+  void* all[qinco::kInstanceNFns] = {
+      reinterpret_cast<void*>(&QINCO_CAT(qinco_mlp_launch_, QD, QDE, QDH, QP, QVAR)),
+      reinterpret_cast<void*>(&QINCO_CAT(qinco_xproj_launch_, QD, QDE, QDH, QP, QVAR)),
+      reinterpret_cast<void*>(&qinco_module_table_launch),
+      reinterpret_cast<void*>(&qinco_module_ivf_launch),
 #ifdef QINCO_MODULE_HAS_SMALL
-  fns[4] = reinterpret_cast<void*>(&qinco_module_small_launch);
+      reinterpret_cast<void*>(&qinco_module_small_launch),
+#else
+      nullptr,
 #endif
+  };
+  for (int i = 0; i < cap && i < qinco::kInstanceNFns; ++i) fns[i] = all[i];
   return qinco::instance_abi();
 }
 #endif

@@ -211,6 +211,13 @@ struct qinco_handle_s {
   // host-path staging: a two-deep pipeline of pinned host buffers and device buffers (HostPipe below)
   struct HostPipe* pipe = nullptr;
 
+  // Every call on a handle works in the SAME scratch (xhat, hist, cand, dist, codes_t, dxhat, uproj, err_flag): calls are ordered
+  // by the stream they are given, and a call on ANOTHER stream than the previous one (torch's current stream, then the host
+  // pipeline's private non-blocking stream; two user streams) first waits for that one's work (scratch_enter / scratch_leave).
+  hipEvent_t scratch_done = nullptr;
+  hipStream_t scratch_stream = nullptr;
+  bool scratch_used = false;
+
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -818,7 +825,7 @@ extern "C" int qinco_load_instance(const char* path) {
   if (!path) return fail(QINCO_ERR_INVALID, "qinco_load_instance: null path");
   void* so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
   if (!so) return fail(QINCO_ERR_INVALID, "qinco_load_instance: %s", dlerror());
-  typedef int (*info_fn)(int32_t*, void**);
+  typedef int (*info_fn)(int32_t*, void**, int);
   info_fn info = reinterpret_cast<info_fn>(dlsym(so, "qinco_instance_info"));
   if (!info) {
     dlclose(so);
@@ -826,8 +833,10 @@ extern "C" int qinco_load_instance(const char* path) {
                                    "with -DQINCO_INSTANCE_MODULE?)", path);
   }
   int32_t v[6] = {0, 0, 0, 0, 0, 0};
-  void* fns[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  const int abi = info(v, fns), want_abi = instance_abi();
+  // (a module from before the capacity argument ignores it and writes its own launcher count: the array is longer than any
+  // count ever exported, and its abi word -- launcher count included since version 4 -- is refused below)
+  void* fns[kInstanceNFns + 8] = {};
+  const int abi = info(v, fns, kInstanceNFns), want_abi = instance_abi();
   if (abi != want_abi || !fns[0] || !fns[1]) {
     dlclose(so);
     return fail(QINCO_ERR_INVALID, "qinco_load_instance: %s was built against another version of csrc/mlp_args.hpp (0x%x vs 0x%x)", path,
@@ -1401,6 +1410,7 @@ extern "C" int qinco_destroy(qinco_handle h) {
   for (void* p : h->owned)
     if (p) (void)hipFree(p);
   host_pipe_destroy(h->pipe);
+  if (h->scratch_done) (void)hipEventDestroy(h->scratch_done);
   for (auto& e : h->ev_pool) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
@@ -1818,6 +1828,18 @@ static int check_common(qinco_handle h, const void* a, const void* b, int64_t n,
   return 0;
 }
 
+static int scratch_enter(qinco_handle_s* h, hipStream_t st) {
+  if (h->scratch_used && h->scratch_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->scratch_done, 0));
+  return 0;
+}
+static int scratch_leave(qinco_handle_s* h, hipStream_t st) {
+  if (!h->scratch_done) HIP_TRY(hipEventCreateWithFlags(&h->scratch_done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(h->scratch_done, st));
+  h->scratch_stream = st;
+  h->scratch_used = true;
+  return 0;
+}
+
 extern "C" int qinco_encode(qinco_handle h, const void* x, int x_dtype, int64_t stride, int64_t n, void* codes_out,
                             int code_dtype, float* xhat_out, int flags, void* stream) {
   int rc = check_common(h, x, codes_out, n, code_dtype, "qinco_encode");
@@ -1829,14 +1851,18 @@ extern "C" int qinco_encode(qinco_handle h, const void* x, int x_dtype, int64_t 
   if (stride < (int64_t)(h->user.D * esz)) return fail(QINCO_ERR_INVALID, "qinco_encode: row stride smaller than a row");
   if ((rc = ensure_scratch(h))) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (n > 0 && (rc = scratch_enter(h, st))) return rc;
   for (int64_t i0 = 0; i0 < n; i0 += h->d.max_batch) {
     int64_t nb = n - i0 < h->d.max_batch ? n - i0 : h->d.max_batch;
     const char* xp = reinterpret_cast<const char*>(x) + i0 * stride;
     char* cp = reinterpret_cast<char*>(codes_out) + (size_t)i0 * h->d.M * code_size(code_dtype);
     float* xo = xhat_out ? xhat_out + (size_t)i0 * h->user.D : nullptr;
-    if ((rc = encode_chunk(h, xp, x_dtype, stride, nb, cp, code_dtype, xo, flags, st))) return rc;
+    if ((rc = encode_chunk(h, xp, x_dtype, stride, nb, cp, code_dtype, xo, flags, st))) {
+      (void)scratch_leave(h, st);   // (what was launched before the failure still owns the scratch)
+      return rc;
+    }
   }
-  return QINCO_OK;
+  return n > 0 ? scratch_leave(h, st) : QINCO_OK;
 }
 
 static int decode_chunk(qinco_handle_s* h, const void* codes, int code_dtype, int64_t n, float* out, int flags,
@@ -1920,12 +1946,16 @@ extern "C" int qinco_decode(qinco_handle h, const void* codes, int code_dtype, i
   HIP_TRY(hipSetDevice(h->device));
   if ((rc = ensure_decode_scratch(h, n))) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (n > 0 && (rc = scratch_enter(h, st))) return rc;
   for (int64_t i0 = 0; i0 < n; i0 += h->dec_cap) {
     int64_t nb = n - i0 < h->dec_cap ? n - i0 : h->dec_cap;
     const char* cp = reinterpret_cast<const char*>(codes) + (size_t)i0 * h->d.M * code_size(code_dtype);
-    if ((rc = decode_chunk(h, cp, code_dtype, nb, out + (size_t)i0 * h->user.D, flags, st))) return rc;
+    if ((rc = decode_chunk(h, cp, code_dtype, nb, out + (size_t)i0 * h->user.D, flags, st))) {
+      (void)scratch_leave(h, st);
+      return rc;
+    }
   }
-  return QINCO_OK;
+  return n > 0 ? scratch_leave(h, st) : QINCO_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1972,6 +2002,9 @@ extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int
   const size_t need[3] = {(size_t)cap * rowb, (size_t)cap * crow, xhat_out ? (size_t)cap * orow : 0};
   if ((rc = host_pipe_ensure(&h->pipe, need))) return rc;
   HostPipe& p = *h->pipe;
+  // the private compute stream is non-blocking: it is ordered behind earlier device-pointer calls on this handle (torch's stream,
+  // the null stream) explicitly -- they work in the same scratch and raise the same flag
+  if ((rc = scratch_enter(h, p.s_comp))) return rc;
   // this call reports its own work only: a flag left behind by an unchecked device-pointer call is dropped
   if (h->split16) HIP_TRY(hipMemsetAsync(h->err_flag, 0, sizeof(int), p.s_comp));
   const int64_t P = (n + pass - 1) / pass;
@@ -2052,6 +2085,7 @@ extern "C" int qinco_decode_host(qinco_handle h, const void* codes, int code_dty
   if ((rc = host_pipe_ensure(&h->pipe, need))) return rc;
   if ((rc = ensure_decode_scratch(h, cap))) return rc;
   HostPipe& p = *h->pipe;
+  if ((rc = scratch_enter(h, p.s_comp))) return rc;   // (see qinco_encode_host)
   // this call reports its own codes only: a flag left behind by an unchecked device-pointer decode is dropped
   HIP_TRY(hipMemsetAsync(h->err_flag, 0, sizeof(int), p.s_comp));
   const int64_t P = (n + pass - 1) / pass;

@@ -307,11 +307,11 @@ class PartFileWriter:
         self._pool.shutdown()
 
 
-def _comm_device(dist, device=None):
+def _comm_device(dist, device=None, group=None):
     """Device the collectives' tensors must live on: RCCL (backend "nccl") moves GPU buffers only, gloo CPU ones."""
     if device is not None:
         return device
-    if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+    if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
         import torch
         return torch.device("cuda", torch.cuda.current_device())
     return None
@@ -383,9 +383,11 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
         np.savez_compressed(output, n_parts=world, K=K, M=M, D=D)
     if writer is not None:
         writer.close()
-    elif done is None and keep:
+    elif done is None and (keep or end == start):
+        # (no writer: writer_threads = 0, or an EMPTY shard -- N < world -- which never reaches the sink: the header says
+        # n_parts = world, so every rank owes the readers a part file, also with keep=False)
         tmp = part + ".tmp.npz"      # (np.savez appends .npz to other suffixes)
-        np.savez_compressed(tmp, codes=codes.astype(np.int64))
+        np.savez_compressed(tmp, codes=(codes if codes is not None else np.zeros((0, M))).astype(np.int64))
         os.replace(tmp, part)
     if world > 1:
         _barrier(dist, device)
@@ -422,31 +424,49 @@ def _load_part(path: str, rows: int, cols=None, header_ok: bool = True) -> Optio
     return codes
 
 
-def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None, code_dtype=np.int64) -> Optional[np.ndarray]:
+def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None, code_dtype=np.int64, group=None,
+                 stats: Optional[dict] = None) -> Optional[np.ndarray]:
     """The per-rank code shards to rank 0: every rank sends its shard once, rank 0 receives each one straight into
     its rows of ONE preallocated (N, M) matrix of the wire type -- uint8 when every code is below 256 (M bytes per vector), else
     the shards' own type -- so the collective costs rank 0 one copy of the payload (8 GB at 10^9 x 8 codes), not a padded bucket
     per rank plus int64 copies of all of them.  Shards may differ in length (the last rank holds the remainder): point-to-point
     transfers (grouped on RCCL) instead of a fixed-size gather.  Returns (N, M) on rank 0 -- `code_dtype` np.int64 (the reference's
-    type) or "compact" (the wire type) -- and the local shard elsewhere."""
+    type) or "compact" (the wire type) -- and the local shard elsewhere.
+
+    group: the process group that carries the payload (default: the default group) -- a job whose default group is a gloo control
+    plane passes its "nccl" sub-group here and the transfers run on RCCL from device buffers.  Call sequence on RCCL, per rank:
+    all_reduce(MAX) of one int32 (the wire type), then rank r > 0: ONE send of its (n_r, M) shard; rank 0: world - 1 irecv, each
+    into its row range of the (N, M) matrix, wait, one D2H copy.  stats (optional dict) receives wire_dtype, bytes_sent,
+    bytes_received, ranks (the group's size as torch.distributed sees it) and the seconds spent in the transfers."""
+    import time
     rank, world = _dist_info(dist)
     compact = isinstance(code_dtype, str) and code_dtype == "compact"
     if world == 1:
         return codes_local if compact else codes_local.astype(code_dtype, copy=False)
     import torch
-    device = _comm_device(dist, device)
+    if group is not None and dist.get_world_size(group) != world:
+        raise ValueError("gather_codes: the payload group must span every rank of the job")
+    device = _comm_device(dist, device, group)
+    t0 = time.perf_counter()
     M = codes_local.shape[1]
     small = codes_local.size == 0 or int(codes_local.max()) < 256
     wide = 0 if small else (1 if codes_local.dtype.itemsize <= 4 and int(codes_local.max()) < 2 ** 31 else 2)
     flag = torch.tensor([wide], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     wire = (np.uint8, np.int32, np.int64)[int(flag.item())]
     mine = torch.from_numpy(np.ascontiguousarray(codes_local, dtype=wire))
     if device is not None:
         mine = mine.to(device)
+    if stats is not None:
+        stats.update(wire_dtype=np.dtype(wire).name, ranks=int(dist.get_world_size(group)), bytes_sent=0, bytes_received=0,
+                     transport=str(dist.get_backend(group)), buffers="device" if device is not None else "host")
     if rank != 0:
         if len(mine):
-            dist.send(mine, dst=0)
+            dist.send(mine, dst=0, group=group)
+            if device is not None:
+                torch.cuda.synchronize(device)       # (RCCL's send returns when it is enqueued: the seconds below are the transfer's)
+        if stats is not None:
+            stats.update(bytes_sent=int(mine.numel() * mine.element_size()), seconds=time.perf_counter() - t0)
         return codes_local
     full = torch.empty((db_size, M), dtype=mine.dtype, device=mine.device)
     s0, e0 = shard_bounds(db_size, world, 0)
@@ -455,10 +475,12 @@ def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None, code_
     for r in range(1, world):
         s, e = shard_bounds(db_size, world, r)
         if e > s:
-            reqs.append(dist.irecv(full[s:e], src=r))
+            reqs.append(dist.irecv(full[s:e], src=r, group=group))
     for q in reqs:
         q.wait()
     out = full.cpu().numpy()
+    if stats is not None:
+        stats.update(bytes_received=int((db_size - (e0 - s0)) * M * mine.element_size()), seconds=time.perf_counter() - t0)
     return out if compact else out.astype(code_dtype, copy=False)
 
 

@@ -87,3 +87,33 @@ def assert_only_near_ties(oracle, x, got, want, near_tie, label=""):
     same = (replay.T == got[bad]).all(axis=1)
     assert same.all(), f"{label}: rows {bad[~same].tolist()} are not reachable by the oracle under a {near_tie:g} perturbation"
     return len(bad)
+
+
+def lut_case_inputs(seed, M, K, D, ivf_K, Mt, n, IVF_M=5):
+    """The seeded inputs of a look-up-decoder fixture case: the same draws, in the same order, as tests/golden/make_golden.py
+    lut_case_inputs (numpy RandomState streams are stable across numpy versions)."""
+    rs = np.random.RandomState(int(seed))
+    M, K, D, ivf_K, Mt, n = (int(v) for v in (M, K, D, ivf_K, Mt, n))
+    cb = rs.randn(Mt, K * K, D).astype(np.float32)
+    comb = rs.randint(0, M + IVF_M, (2, Mt)).astype(np.int64)
+    comb[:, 0] = (0, M)
+    comb[:, 1] = (1, 2)
+    imap = rs.randint(0, K, (ivf_K, IVF_M)).astype(np.int64)
+    codes_MB = rs.randint(0, K, (M, n)).astype(np.int64)
+    ivf = rs.randint(0, ivf_K, n).astype(np.int64)
+    return cb, comb, imap, codes_MB, ivf
+
+
+def lut_fixture_cases():
+    """-> list of (label, codebook_MKD, combine_mvals_m, K_base, ivf_code_map, codes_MB, ivf_codes, mapped, xhat) of
+    tests/golden/lut_decoders.npz: what the REFERENCE's PairwiseDecoderIVF.map_codes / forward returned for these inputs."""
+    g = load_golden("lut_decoders")
+    out = []
+    for name in ("small", "wide"):
+        kw = {k: int(g[f"pw_{name}_{k}"]) for k in ("seed", "M", "K", "D", "ivf_K", "Mt", "n")}
+        cb, comb, imap, codes_MB, ivf = lut_case_inputs(**kw)
+        if name == "small":     # stored whole: also pins the regeneration recipe itself
+            for got, key in ((cb, "codebook_MKD"), (comb, "combine"), (imap, "ivf_code_map"), (codes_MB, "codes_MB"), (ivf, "ivf")):
+                assert np.array_equal(got, g[f"pw_small_{key}"]), key
+        out.append((name, cb, comb, kw["K"], imap, codes_MB, ivf, g[f"pw_{name}_mapped"], g[f"pw_{name}_xhat"]))
+    return out

@@ -30,7 +30,7 @@ from qinco.model import QINCo, QINCoInferenceWrapper  # noqa: E402  (the referen
 from qinco.model.qinco_base import IVFBook  # noqa: E402
 
 sys.path.insert(0, str(HERE))
-from cases import CASES, case_model, clustered_rows  # noqa: E402  (the case table, shared with tests/conftest.py)
+from cases import CASES, case_model, clustered_rows, rerank_lut_tables  # noqa: E402  (the case table, shared with tests/conftest.py)
 from qinco_amd.config import QincoConfig  # noqa: E402
 from qinco_amd.synth import regime_vectors, synth_codes, synth_vectors  # noqa: E402
 from oracle.qinco_oracle import OracleQINCo  # noqa: E402
@@ -206,15 +206,103 @@ def run_search_case() -> dict:
             "dist_sorted": dsorted.astype(np.float32), "recalls": np.asarray(recalls, np.float64)}
 
 
+def import_reference_search_modules():
+    """-> (qinco.search.pairwise_decoder, qinco.search.search_utils) of the reference, imported in this container.
+
+    qinco/search/search_utils.py does `import faiss` at module level and qinco/search/pairwise_decoder.py imports qinco/metrics.py,
+    whose two metric classes subclass torcheval.metrics.Metric; neither package is installed here (no network).  NONE of the
+    reference lines driven by run_lut_case / run_rerank_case touches either of them (PairwiseDecoderIVF.forward / map_codes are
+    three indexing statements on nn.Parameters, reconstruct_from_fixed_codebooks is numpy indexing): for the duration of the two
+    imports EMPTY placeholder modules stand in sys.modules -- `faiss` with no attribute at all, `torcheval.metrics` with a bare
+    `Metric` class for the two class statements to name as a base -- and are removed again before anything runs.  They implement
+    nothing; a reference line that needed the real packages would raise AttributeError here."""
+    import types
+    added = [n for n in ("faiss", "torcheval", "torcheval.metrics") if n not in sys.modules]
+    for n in added:
+        sys.modules[n] = types.ModuleType(n)
+    if "torcheval.metrics" in added:
+        sys.modules["torcheval.metrics"].Metric = type("Metric", (), {})
+        sys.modules["torcheval"].metrics = sys.modules["torcheval.metrics"]
+    try:
+        from qinco.search import pairwise_decoder, search_utils
+    finally:
+        for n in added:
+            del sys.modules[n]
+    return pairwise_decoder, search_utils
+
+
+def reference_pairwise_decoder(pd_mod, codebook_MKD, combine_mvals_m, K_base, ivf_code_map):
+    """A PairwiseDecoderIVF of the reference with its inference state filled in by hand: the constructor trains or loads a file
+    (pairwise_decoder.py:19-58); forward / map_codes (:88-93, :126-130) read exactly these four attributes."""
+    dec = pd_mod.PairwiseDecoderIVF.__new__(pd_mod.PairwiseDecoderIVF)
+    torch.nn.Module.__init__(dec)
+    dec.K_base = int(K_base)
+    dec.codebook_MKD = torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(codebook_MKD, dtype=np.float32)), requires_grad=False)
+    dec.combine_mvals_m = torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(combine_mvals_m, dtype=np.int64)), requires_grad=False)
+    dec.ivf_code_map = torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(ivf_code_map, dtype=np.int64)), requires_grad=False)
+    return dec
+
+
+def lut_case_inputs(seed: int, M: int, K: int, D: int, ivf_K: int, Mt: int, n: int, IVF_M: int = 5):
+    """Seeded inputs of a look-up-decoder case (the tests regenerate the large ones from the seed instead of storing them)."""
+    rs = np.random.RandomState(seed)
+    cb = rs.randn(Mt, K * K, D).astype(np.float32)
+    comb = rs.randint(0, M + IVF_M, (2, Mt)).astype(np.int64)
+    comb[:, 0] = (0, M)                 # at least one pair reads an IVF-map column, one a plain pair of steps
+    comb[:, 1] = (1, 2)
+    imap = rs.randint(0, K, (ivf_K, IVF_M)).astype(np.int64)
+    codes_MB = rs.randint(0, K, (M, n)).astype(np.int64)
+    ivf = rs.randint(0, ivf_K, n).astype(np.int64)
+    return cb, comb, imap, codes_MB, ivf
+
+
+LUT_CASES = {"small": dict(seed=77, M=8, K=16, D=32, ivf_K=200, Mt=11, n=500),          # stored whole
+             "wide": dict(seed=78, M=8, K=64, D=128, ivf_K=4096, Mt=12, n=1000)}         # 25 MB of tables: regenerated from the seed
+
+
+def run_lut_case() -> dict:
+    """SURVEY 8f4's look-up decoders, recorded from the REFERENCE's own code (import_reference_search_modules):
+    PairwiseDecoderIVF.forward (qinco/search/pairwise_decoder.py:88-93) with map_codes (:126-130) -- which always takes the IVF ids
+    (it asserts their shape) -- and reconstruct_from_fixed_codebooks (qinco/search/search_utils.py:105-115), whose input has no
+    IVF column."""
+    pd_mod, su_mod = import_reference_search_modules()
+    assert pd_mod.PairwiseDecoderIVF.IVF_M == 5
+    out = {}
+    for name, kw in LUT_CASES.items():
+        cb, comb, imap, codes_MB, ivf = lut_case_inputs(**kw)
+        dec = reference_pairwise_decoder(pd_mod, cb, comb, kw["K"], imap)
+        with torch.no_grad():
+            mapped = dec.map_codes(torch.from_numpy(codes_MB), torch.from_numpy(ivf))
+            xhat = dec(torch.from_numpy(codes_MB), torch.from_numpy(ivf))
+            xhat32 = dec(torch.from_numpy(codes_MB.astype(np.int32)), torch.from_numpy(ivf.astype(np.int32)))    # (the search hands over int32 columns)
+        assert torch.equal(xhat, xhat32)
+        out[f"pw_{name}_mapped"] = mapped.numpy()
+        out[f"pw_{name}_xhat"] = xhat.numpy()
+        for k, v in kw.items():
+            out[f"pw_{name}_{k}"] = np.int64(v)
+        if name == "small":
+            out.update(pw_small_codebook_MKD=cb, pw_small_combine=comb, pw_small_ivf_code_map=imap, pw_small_codes_MB=codes_MB, pw_small_ivf=ivf)
+        print(f"lut_decoders pairwise {name:6s} n={kw['n']} Mt={kw['Mt']} K^2={kw['K'] ** 2} D={kw['D']}")
+    rs = np.random.RandomState(79)
+    for name, (n, M, K, D, dt) in {"u8": (700, 8, 256, 32, np.uint8), "i64": (257, 16, 64, 96, np.int64), "one": (1, 4, 64, 32, np.int32)}.items():
+        cbs = rs.randn(M, K, D).astype(np.float32)
+        codes = rs.randint(0, K, (n, M)).astype(dt)
+        rec = su_mod.reconstruct_from_fixed_codebooks(codes, cbs)
+        out.update({f"fixed_{name}_codebooks": cbs, f"fixed_{name}_codes": codes, f"fixed_{name}_recons": np.asarray(rec, np.float32)})
+        print(f"lut_decoders fixed    {name:6s} n={n} M={M} K={K} D={D}")
+    return out
+
+
 def run_rerank_case() -> dict:
     """The re-rank stages of run_search_ivf (qinco/search/search_tasks.py:447-507; the module itself needs faiss to import), driven
     line by line with the reference's own pieces: compute_batch_distances(approx=True) (qinco/utils.py:349-383), torch.argsort /
     take_along_dim, and the reference's inference wrapper for the QINCo decode in batches of cfg.search.batch_size.  The shortlist
     that faiss's index.search_and_return_codes would hand over is made here (each query's true neighbours among its own
-    reconstructions + random rows), and so is the mid re-ranker's output: PairwiseDecoderIVF cannot be imported (torcheval), its
-    reconstructions enter as a given (n, d) array built from a look-up table with this repo's own formula -- that look-up stays
-    "parity unpinned"; everything downstream of it is the reference's arithmetic."""
+    reconstructions + random rows).  The mid re-ranker is the reference's own PairwiseDecoderIVF (import_reference_search_modules)
+    called exactly as search_tasks.py:451 calls it -- mid_reranker(codes_int32_T[1:], codes_int32_T[0]) -- over look-up tables made
+    from the model's codebooks and a seeded ivf_code_map: every stage of the fixture is the reference's arithmetic."""
     from qinco.utils import compute_batch_distances
+    pd_mod, _ = import_reference_search_modules()
     cfg, sd = case_model("tiny_ivf_beam")
     model, wrapper = build_reference(cfg, sd)
     M, d = cfg.M, cfg.D
@@ -233,17 +321,15 @@ def run_rerank_case() -> dict:
     codes_int32 = codes_db[I.reshape(-1)]                                                     # (nq * n_short_ivf, M + 1)
     # the mid re-ranker's stand-in: a pairwise look-up table T[j][c_a K + c_b] over (step 1, step 2), ..., rough reconstructions
     K = cfg.K
-    pairs = [(0, 1), (1, 2)] if M >= 3 else [(0, 1)]
-    cb = [np.asarray(sd[f"steps.{m + 1}.codebook.weight"], np.float32) for m in range(M)]
-    tables = np.stack([(cb[a][:, None, :] + 0.5 * cb[b][None, :, :]).reshape(K * K, d) for a, b in pairs]).astype(np.float32)
-    comb = np.array([[a for a, _ in pairs], [b for _, b in pairs]], np.int64)
-    qc = codes_int32[:, 1:].astype(np.int64)
-    mid = np.zeros((len(qc), d), np.float32)
-    for j in range(len(pairs)):
-        mid = mid + tables[j][qc[:, comb[0, j]] * K + qc[:, comb[1, j]]]
+    tables, comb = rerank_lut_tables(cfg, sd)
+    ivf_code_map = np.random.RandomState(93).randint(0, K, (cfg.ivf_K, pd_mod.PairwiseDecoderIVF.IVF_M)).astype(np.int64)
+    mid_reranker = reference_pairwise_decoder(pd_mod, tables, comb, K, ivf_code_map)
+    with torch.no_grad():
+        ct = torch.from_numpy(codes_int32).T
+        mid = mid_reranker(ct[1:], ct[0]).numpy()                                             # search_tasks.py:451
     ivf_book_t = model.steps[0].ivf_centroids.weight.detach()
-    # (the tables are a function of the model's codebooks: the test rebuilds them with the same two lines instead of storing 16 MB)
-    out = {"xq": xq, "I": I, "codes_int32": codes_int32, "pair_combine": comb, "mid_shortlist": mid,
+    # (the tables are a function of the model's codebooks: the test rebuilds them with rerank_lut_tables instead of storing 25 MB)
+    out = {"xq": xq, "I": I, "codes_int32": codes_int32, "pair_combine": comb, "ivf_code_map": ivf_code_map, "mid_shortlist": mid,
            "ivf_book": ivf_book_t.numpy(), "nshort": np.int64(nshort), "batch_size": np.int64(bs)}
     with torch.no_grad():
         xq_distances = torch.from_numpy(xq)
@@ -276,6 +362,8 @@ def run_rerank_case() -> dict:
 
 if __name__ == "__main__":
     only = sys.argv[1:]
+    if not only or "lut_decoders" in only:
+        np.savez_compressed(HERE / "lut_decoders.npz", **run_lut_case())
     if not only or "rerank_ivf" in only:
         np.savez_compressed(HERE / "rerank_ivf.npz", **run_rerank_case())
     if not only or "search_small_db" in only:

@@ -147,8 +147,14 @@ def test_kernel_instance_built_on_demand_and_registered(lib):
     else:
         assert so.exists() and lib.qinco_shape_supported(100, 256, 500) == 1
         mod = C.CDLL(str(so))
-        v, fns = (C.c_int32 * 6)(), (C.c_void_p * 4)()
-        assert mod.qinco_instance_info(v, fns) > (1 << 16) and list(v)[:5] == [128, 256, 512, 48, 124] and all(fns[i] for i in range(4))
+        # the capacity argument bounds what the module writes: a short array stays short (round 4: a 4-slot array under a
+        # 5-launcher module was 8 bytes of heap corruption and took the whole CPU tier down with it)
+        v, fns = (C.c_int32 * 6)(), (C.c_void_p * 8)()
+        C.memset(fns, 0xEE, C.sizeof(fns))
+        abi = mod.qinco_instance_info(v, fns, 4)
+        assert abi > (1 << 16) and list(v)[:5] == [128, 256, 512, 48, 124] and all(fns[i] for i in range(4))
+        assert all(fns[i] == 0xEEEEEEEEEEEEEEEE for i in range(4, 8)), "qinco_instance_info wrote past its capacity"
+        assert mod.qinco_instance_info(v, fns, 8) == abi and fns[5] == 0xEEEEEEEEEEEEEEEE    # kInstanceNFns = 5 launchers, no more
         assert ensure_instance(100, 256, 500) is None             # second call: nothing to do
 
 

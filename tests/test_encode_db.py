@@ -281,3 +281,113 @@ print("PEAK_MB", (peak - base) / 1024.0)
     assert r.returncode == 0, r.stdout + r.stderr
     peak_mb = float(r.stdout.split("PEAK_MB")[1])
     assert peak_mb < 1200, f"peak resident growth {peak_mb:.0f} MB for a 400 MB byte payload"
+
+
+def _payload_group_worker(rank, world, port, outdir, n):
+    """gather_codes on a payload group that is NOT the default group (bench.py: gloo control plane + a sub-group for the codes)."""
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qinco_amd.encode_db import gather_codes, shard_bounds
+    payload = dist.new_group(backend="gloo")
+    s, e = shard_bounds(n, world, rank)
+    rows = np.arange(s, e, dtype=np.int64)[:, None]
+    mine = ((rows * 7 + np.arange(5)[None, :]) % 256).astype(np.uint8)
+    if n == 3 * 41 + 2:                       # one job also carries a wide column (an IVF id): the wire type widens on every rank
+        mine = mine.astype(np.int32)
+        mine[:, 0] = rows[:, 0] * 1000
+    stats = {}
+    full = gather_codes(mine, n, dist, code_dtype="compact", group=payload, stats=stats)
+    np.save(os.path.join(outdir, f"stats_{rank}.npy"), np.array([stats["ranks"], stats["bytes_sent"], stats["bytes_received"]]))
+    if rank == 0:
+        np.save(os.path.join(outdir, "full.npy"), full)
+        open(os.path.join(outdir, "wire.txt"), "w").write(stats["wire_dtype"] + " " + stats["transport"] + " " + stats["buffers"])
+    else:
+        assert full is mine
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 101), (3, 3 * 41 + 2), (8, 8 * 13 + 5), (4, 2)])
+def test_gather_codes_on_a_payload_group_gloo(tmp_path, world, n):
+    """The end-of-job transfer at 2, 3 and 8 ranks (uneven last shard; N < world: empty shards send nothing): rank 0's matrix is the
+    database's codes in file order, and the stats say what moved."""
+    import torch.multiprocessing as mp
+    from qinco_amd.encode_db import shard_bounds
+    mp.spawn(_payload_group_worker, args=(world, _free_port(), str(tmp_path), n), nprocs=world, join=True)
+    rows = np.arange(n, dtype=np.int64)[:, None]
+    want = (rows * 7 + np.arange(5)[None, :]) % 256
+    wide = n == 3 * 41 + 2
+    if wide:
+        want[:, 0] = rows[:, 0] * 1000
+    full = np.load(tmp_path / "full.npy")
+    assert full.dtype == (np.int32 if wide else np.uint8) and np.array_equal(full, want)
+    assert open(tmp_path / "wire.txt").read() == ("int32" if wide else "uint8") + " gloo host"
+    isz = 4 if wide else 1
+    for r in range(world):
+        s, e = shard_bounds(n, world, r)
+        ranks, sent, recv = np.load(tmp_path / f"stats_{r}.npy")
+        assert ranks == world and sent == (0 if r == 0 else (e - s) * 5 * isz)
+        assert recv == ((n - (shard_bounds(n, world, 0)[1])) * 5 * isz if r == 0 else 0)
+
+
+def _keep_false_worker(rank, world, port, outdir, n):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qinco_amd import synth_vectors
+    from qinco_amd.encode_db import encode_database
+    model = OracleModel("tiny_proj_greedyA")
+    cfg = model.cfg
+    db = synth_vectors(cfg, model.sd, n, seed=4)
+    assert encode_database(model, db, os.path.join(outdir, "db.npz"), K=cfg.K, M=cfg.M, D=cfg.D, batch=50, dist=dist, keep=False) is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_empty_shards_write_their_part_files_with_keep_false_gloo(tmp_path):
+    """N < world: the ranks in front hold EMPTY shards (search_tasks.py:103-104 gives the remainder to the last one).  The header
+    says n_parts = world, so each of them owes the readers a part file -- also in the part-files-only mode (keep=False), where
+    round 4 wrote none and EncodedDBIterator failed on the missing file."""
+    import torch.multiprocessing as mp
+    from qinco_amd import synth_vectors
+    from qinco_amd.encode_db import EncodedDBIterator
+    world, n = 3, 2
+    mp.spawn(_keep_false_worker, args=(world, _free_port(), str(tmp_path), n), nprocs=world, join=True)
+    model = OracleModel("tiny_proj_greedyA")
+    want = model(synth_vectors(model.cfg, model.sd, n, seed=4), step="encode").T
+    it = EncodedDBIterator(str(tmp_path / "db.npz"))
+    assert it.n_parts == world and np.array_equal(it.load_all(), want)
+    assert [len(np.load(tmp_path / f"db.part_{r}.npz")["codes"]) for r in range(world)] == [0, 0, 2]
+    assert all(np.load(tmp_path / f"db.part_{r}.npz")["codes"].dtype == np.int64 for r in range(world))
+
+
+def test_rccl_id_file_is_matched_by_nonce_not_by_clock(tmp_path):
+    """RcclComm's id exchange (qinco_amd/comm.py), the waiting ranks' side -- no RCCL call is made here.  With a job nonce a file is
+    this job's iff it ends in the nonce: a day-old file with the right nonce is taken (a rank may start arbitrarily late, clocks
+    may disagree), a brand-new file of another job is not.  Without a nonce the single-host rule applies: not older than
+    timeout_s before this rank's start."""
+    import time
+    from qinco_amd.comm import RcclComm
+    c = RcclComm.__new__(RcclComm)
+    f = str(tmp_path / "uid")
+    blob = bytes(range(128))
+    open(f, "wb").write(blob + b"job-41")
+    old = time.time() - 86400
+    os.utime(f, (old, old))
+    uid = c._exchange_through_file(1, f, 0.3, "job-41")
+    assert bytes(uid.internal) == blob
+    with pytest.raises(TimeoutError, match="job-42"):
+        c._exchange_through_file(1, f, 0.3, "job-42")                       # another job's file, however fresh
+    open(f, "wb").write(blob)                                               # no nonce: the mtime rule, with timeout_s of slack
+    assert bytes(c._exchange_through_file(2, f, 5.0, None).internal) == blob
+    os.utime(f, (old, old))
+    with pytest.raises(TimeoutError):
+        c._exchange_through_file(2, f, 0.3, None)
+    with pytest.raises(ValueError):
+        RcclComm.__new__(RcclComm).__init__(0, 1)                           # neither an id nor a way to get one

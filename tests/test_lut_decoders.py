@@ -1,5 +1,6 @@
-"""look-up decoders (HBM-bound gather-add) against the oracle restatement -- bit-exact (fp32 adds in the
-reference's order).  Parity is UNPINNED for this row: the reference modules need faiss / torcheval to import."""
+"""look-up decoders (HBM-bound gather-add) -- bit-exact (fp32 adds in the reference's order) against
+tests/golden/lut_decoders.npz, i.e. against what the REFERENCE's own PairwiseDecoderIVF.forward / map_codes and
+reconstruct_from_fixed_codebooks returned (make_golden.py run_lut_case), and against the oracle restatement on fresh inputs."""
 import numpy as np
 import pytest
 
@@ -39,3 +40,24 @@ def test_pairwise_decoder_bit_exact_and_device_path():
     cols = torch.from_numpy(dec.gather_codes(codes_MB, ivf)).cuda()
     assert np.array_equal(dec._dec(cols).cpu().numpy(), want)
     dec.close()
+
+
+def test_lookup_decoders_equal_the_reference_fixture():
+    """The pin of row f4: lut_decode_kernel through qinco_amd.lut against the reference's recorded outputs -- same bits, host path and
+    device path, int64 and int32 code columns (the search hands over int32, search_tasks.py:427-445)."""
+    import torch
+    from conftest import load_golden, lut_fixture_cases
+    from qinco_amd.lut import PairwiseDecoder, reconstruct_from_fixed_codebooks
+    for name, cb, comb, K, imap, codes_MB, ivf, mapped, xhat in lut_fixture_cases():
+        dec = PairwiseDecoder(cb, comb, K, imap)
+        cols = dec.gather_codes(codes_MB, ivf)
+        assert np.array_equal(cols[:, comb[0]] * K + cols[:, comb[1]], mapped.T), name     # the columns map_codes combines
+        got = dec(codes_MB, ivf)
+        assert got.dtype == np.float32 and np.array_equal(got, xhat), name
+        assert np.array_equal(dec(codes_MB.astype(np.int32), ivf.astype(np.int32)), xhat), name
+        assert np.array_equal(dec._dec(torch.from_numpy(cols.astype(np.int32)).cuda()).cpu().numpy(), xhat), name
+        dec.close()
+    g = load_golden("lut_decoders")
+    for name in ("u8", "i64", "one"):
+        got = reconstruct_from_fixed_codebooks(g[f"fixed_{name}_codes"], g[f"fixed_{name}_codebooks"])
+        assert np.array_equal(got, g[f"fixed_{name}_recons"]), name

@@ -205,8 +205,8 @@ def test_rerank_ivf_matches_the_reference_stages():
     """run_search_ivf's re-rank stages (search_tasks.py:447-507) as qinco_amd.search.rerank_ivf over the look-up decoder, the
     re-rank kernel (csrc/rerank_kernel.hpp) and QINCoHIP's decode in batches, against a fixture made by driving those lines with
     the reference's own compute_batch_distances, argsort / take_along_dim and inference wrapper (tests/golden/make_golden.py
-    run_rerank_case).  The look-up decoder's own arithmetic is "parity unpinned" (PairwiseDecoderIVF needs torcheval to import): its
-    output is checked against this repo's formula only (mid_shortlist); everything downstream is the reference's.
+    run_rerank_case).  The mid re-ranker of the fixture is the reference's own PairwiseDecoderIVF, called as search_tasks.py:451
+    calls it: the look-up decoder's output (mid_shortlist) must be the same bits, and everything downstream is the reference's too.
     A kept id may differ from the reference's only where the reference's own sorted distances are within rounding of each other."""
     import torch
     from conftest import golden_model, load_golden
@@ -216,15 +216,15 @@ def test_rerank_ivf_matches_the_reference_stages():
     g = load_golden("rerank_ivf")
     cfg, sd = golden_model("tiny_ivf_beam")
     K, d, M = cfg.K, cfg.D, cfg.M
-    comb = g["pair_combine"]
-    cb = [np.asarray(sd[f"steps.{m + 1}.codebook.weight"], np.float32) for m in range(M)]
-    tables = np.stack([(cb[a][:, None, :] + 0.5 * cb[b][None, :, :]).reshape(K * K, d) for a, b in comb.T]).astype(np.float32)
-    dec = PairwiseDecoder(tables, comb, K_base=K)
-    mid = dec(g["codes_int32"][:, 1:].T)
-    assert np.abs(np.asarray(mid) - g["mid_shortlist"]).max() <= 1e-5 * np.abs(g["mid_shortlist"]).max()
+    from cases import rerank_lut_tables
+    tables, comb = rerank_lut_tables(cfg, sd)
+    assert np.array_equal(comb, g["pair_combine"])
+    dec = PairwiseDecoder(tables, comb, K_base=K, ivf_code_map=g["ivf_code_map"])
+    mid = dec(g["codes_int32"][:, 1:].T, g["codes_int32"][:, 0])
+    assert np.array_equal(np.asarray(mid), g["mid_shortlist"])       # gathers + fp32 adds in the reference's order: the same bits
     model = QINCoHIP(cfg, sd, max_batch=1024)
     nshort, bs = int(g["nshort"]), int(g["batch_size"])
-    out = rerank_ivf(model, g["xq"], g["I"], g["codes_int32"], nshort=nshort, mid_reranker=lambda c, i: dec(c.cpu().numpy()),
+    out = rerank_ivf(model, g["xq"], g["I"], g["codes_int32"], nshort=nshort, mid_reranker=lambda c, i: dec(c.cpu().numpy(), i.cpu().numpy()),
                      ivf_book=g["ivf_book"], batch_size=bs)
     torch.cuda.synchronize()
 

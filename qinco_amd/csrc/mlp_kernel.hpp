@@ -655,8 +655,17 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
       // (select.hpp: sel_key, ties -> lower index) -- is the number of keys below its own: C / 2 LDS reads per lane, all rows at once,
       // no serial chain at the end of the workgroup's life (a one-wave wave_top_t here cost 6 % of a qinco2-S encode).  Ranks are a
       // permutation of 0 .. C-1: rank < T = winner, and the rank is its place in the next beam.
+#if defined(QINCO_EXPERIMENT) && defined(QINCO_EXP_SELEP_SECOND_LDS)
+      // experiment builds (scripts/exp_isa_lint_red.py): the rounds-3/4 layout -- the keys in LDS objects of their own -- which makes
+      // hipcc drain the weight ring in front of its reads; kept to show that tests/test_isa.py turns red on it
+      __shared__ unsigned long long sel_keys_own[128];
+      __shared__ int sel_idx_own[128];
+      unsigned long long* const sel_keys = sel_keys_own;
+      int* const sel_idx = sel_idx_own;
+#else
       unsigned long long* const sel_keys = reinterpret_cast<unsigned long long*>(lds_ring + RING4);   // [128]
       int* const sel_idx = reinterpret_cast<int*>(lds_ring + RING4 + 64);                              // [128]
+#endif
       auto lds_barrier = [&]() QINCO_LAMBDA {   // (raw: __syncthreads would also wait for the ring's tail DMAs)
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)

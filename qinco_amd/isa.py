@@ -57,6 +57,14 @@ class Kernel:
     name: str                      # mangled symbol
     meta: dict                     # the kernel's entry of the AMDGPU metadata note
     text: list = field(default_factory=list)     # disassembly, one instruction per entry ("mnemonic operands")
+    addr: list = field(default_factory=list)     # byte offset of each instruction from the kernel's first one
+    target: list = field(default_factory=list)   # branches: byte offset of the destination (None for everything else)
+
+    def loops(self) -> list:
+        """[(first, last)] instruction index ranges of the backward branches (a loop body with its closing branch), outermost first."""
+        at = {a: i for i, a in enumerate(self.addr)}
+        out = [(at[t], i) for i, t in enumerate(self.target) if t is not None and t <= self.addr[i] and t in at]
+        return sorted(out, key=lambda r: r[0] - r[1])
 
 
 def _metadata(elf_path: str) -> list[dict]:
@@ -73,20 +81,26 @@ def kernels(elf: bytes) -> list[Kernel]:
         p = Path(d) / "co.elf"
         p.write_bytes(elf)
         metas = {m[".name"]: m for m in _metadata(str(p))}
-        dis = subprocess.run([tool("llvm-objdump"), "-d", "--no-show-raw-insn", "--no-leading-addr", str(p)], check=True, capture_output=True,
-                             text=True).stdout
-    out, cur = {}, None
+        dis = subprocess.run([tool("llvm-objdump"), "-d", "--no-show-raw-insn", str(p)], check=True, capture_output=True, text=True).stdout
+    out, cur, start = {}, None, 0
     for line in dis.splitlines():
-        m = re.match(r"^[0-9a-f]* ?<([^>]+)>:$", line.strip())
+        m = re.match(r"^([0-9a-f]+) <([^>]+)>:$", line.strip())
         if m:
-            cur = m.group(1)
+            cur, start = m.group(2), int(m.group(1), 16)
             if cur in metas:
                 out[cur] = Kernel(cur, metas[cur])
             continue
-        if cur in out:
-            ins = line.split("//")[0].strip()
-            if ins and not ins.endswith(":"):
-                out[cur].text.append(re.sub(r"\s+", " ", ins))
+        if cur in out and "//" in line:
+            ins, _, com = line.partition("//")
+            ins = re.sub(r"\s+", " ", ins.strip())
+            am = re.match(r"\s*([0-9A-Fa-f]+):", com)
+            if not ins or not am:
+                continue
+            k = out[cur]
+            k.text.append(ins)
+            k.addr.append(int(am.group(1), 16) - start)
+            tm = re.search(r"<[^>+]+\+0x([0-9a-f]+)>\s*$", com) if ins.startswith(("s_cbranch", "s_branch")) else None
+            k.target.append(int(tm.group(1), 16) if tm else (0 if ins.startswith(("s_cbranch", "s_branch")) and com.rstrip().endswith(f"<{cur}>") else None))
     return list(out.values())
 
 
@@ -148,6 +162,46 @@ def stats(k: Kernel) -> dict:
                     break
                 if is_mfma(t[j]) or t[j].startswith(("global_", "buffer_", "flat_", "scratch_", "ds_write", "ds_store", "s_barrier")):
                     break
+    # the hot loop: the backward-branch region with the most MFMAs (the FFN-block loop of the fused-MLP kernels)
+    loop = max(((a, b) for a, b in k.loops()), key=lambda r: sum(is_mfma(x) for x in t[r[0]:r[1] + 1]), default=None)
+    body = t[loop[0]:loop[1] + 1] if loop else []
     return {"insts": len(t), "mfma": len(mf), "vmcnt0_in_mfma_span": vm0, "vmcnt0_before_ds_read": vm0_ds,
             "scratch_insts": sum(ins.startswith("scratch_") for ins in t),
-            "lds_dma": sum("global_load_lds" in ins for ins in t)}
+            "lds_dma": sum("global_load_lds" in ins for ins in t),
+            "loop_insts": len(body), "loop_mfma": sum(is_mfma(x) for x in body),
+            "loop_vmcnt0": sum(vmcnt_of(x) == 0 for x in body), "loop_scratch": sum(x.startswith("scratch_") for x in body),
+            "loop_lgkmcnt0": sum(lgkmcnt_of(x) == 0 for x in body)}
+
+
+def lgkmcnt_of(ins: str):
+    m = _WAIT.match(ins)
+    if not m:
+        return None
+    v = re.search(r"lgkmcnt\((\d+)\)", m.group(1))
+    return int(v.group(1)) if v else None
+
+
+def hoisted_loads_in_front_of_ring_dmas(k: Kernel) -> list:
+    """Indices of plain vector-memory loads that sit between a counted `s_waitcnt vmcnt(N)` and the LDS-DMA (global_load_lds) issued
+    behind it.  In the small-launch kernel a ring read is  wait -> ds_read -> DMA of the refill  and every other load of the wave is
+    HOSTED behind that DMA: the wait counts of later reads are raised by exactly the number of such loads (hosted_extra), which is only
+    right while they stay younger than the DMA.  HISTORY.md round 4: without the fence hipcc hoisted them and one wave in thousands
+    consumed a fragment that had not landed."""
+    bad, t = [], k.text
+    for i, ins in enumerate(t):
+        if "global_load_lds" not in ins:
+            continue
+        seen, ring_read = [], False
+        for j in range(i - 1, max(i - 60, -1), -1):
+            if "global_load_lds" in t[j]:
+                break                                # the ring prologue's back-to-back DMAs: no read in between
+            if t[j].startswith(("ds_read", "ds_load")):
+                ring_read = True
+            if vmcnt_of(t[j]) is not None:
+                if ring_read:
+                    bad += seen                      # a ring read: wait -> ds_read -> this DMA, with plain loads in between
+                break
+            if t[j].startswith(("global_load", "buffer_load", "flat_load")):
+                seen.append(j)
+    return bad
+

@@ -29,15 +29,16 @@ def main():
             if sub and sub not in k.name:
                 continue
             st = isa.stats(k)
+            st["hoisted"] = len(isa.hoisted_loads_in_front_of_ring_dmas(k)) if "mlp_small" in k.name else 0
             rows.append((k.name, k.meta, st))
             if dump:
                 dump.mkdir(parents=True, exist_ok=True)
                 (dump / (isa.short_name(k.name).replace("<", "_").replace(">", "").replace(",", "_").replace(" ", "") + ".s")).write_text("\n".join(k.text))
-    print(f"{'kernel':70s} {'vgpr':>5s} {'agpr':>5s} {'scr':>4s} {'spill':>5s} {'lds':>7s} {'insts':>7s} {'mfma':>6s} {'vm0':>4s} {'vm0@ds':>6s}")
+    print(f"{'kernel':70s} {'vgpr':>5s} {'agpr':>5s} {'scr':>4s} {'spill':>5s} {'lds':>7s} {'insts':>7s} {'mfma':>6s} {'vm0':>4s} {'vm0@ds':>6s} {'loop':>6s} {'l.mfma':>6s} {'l.vm0':>5s} {'l.scr':>5s} {'hoist':>5s}")
     for name, m, st in sorted(rows):
         print(f"{isa.short_name(name)[:70]:70s} {m['.vgpr_count']:5d} {m['.agpr_count']:5d} {m['.private_segment_fixed_size']:4d} "
               f"{m['.vgpr_spill_count']:5d} {m['.group_segment_fixed_size']:7d} {st['insts']:7d} {st['mfma']:6d} {st['vmcnt0_in_mfma_span']:4d} "
-              f"{st['vmcnt0_before_ds_read']:6d}")
+              f"{st['vmcnt0_before_ds_read']:6d} {st['loop_insts']:6d} {st['loop_mfma']:6d} {st['loop_vmcnt0']:5d} {st['loop_scratch']:5d} {st['hoisted']:5d}")
 
 
 if __name__ == "__main__":

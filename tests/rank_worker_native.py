@@ -24,7 +24,7 @@ def main():
     x = synth_vectors(cfg, sd, n, seed=4)
     s, e = shard_bounds(n, world, rank)
     codes = model.engine.encode(torch.from_numpy(x[s:e]).cuda(), code_dtype=np.uint8)
-    comm = RcclComm(rank, world, id_file)
+    comm = RcclComm(rank, world, id_file, nonce=outdir.name)      # (the job's nonce: pytest's per-test directory)
     counts = [shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)]
     out = gather_codes_native(codes, counts, rank, root=0, comm=comm)
     if rank == 0:

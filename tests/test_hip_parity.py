@@ -1228,3 +1228,37 @@ def test_long_codes_wide_beams_and_the_candidate_limit():
     with pytest.raises(NotImplementedError, match="candidates per vector"):
         eng.encode(synth_vectors(cfg, synth_state_dict(cfg, 78), 8, seed=1))
     eng.close()
+
+
+def test_host_calls_are_ordered_behind_device_calls_on_the_same_engine():
+    """A handle's calls share one scratch (xhat, hist, cand, dist, codes_t ...).  The device-pointer path is asynchronous on the
+    caller's stream, the host-pointer path runs on the library's private non-blocking stream: a host call issued right behind a
+    device call must WAIT for it (round 4 did not: the two overlapped in the scratch and the first call's codes could be corrupted
+    silently), and so must a device call on another stream.  A long device encode is queued, then a host encode, a host decode and
+    a device encode on a side stream of other vectors -- every result must be what the same call gives alone."""
+    import torch
+    from qinco_amd import QincoEngine, synth_vectors
+    cfg, sd = golden_model("C2_qinco2L_8x8_b8")          # ~60 ms of kernels per 1024 vectors: long enough to overlap with
+    eng = QincoEngine(cfg, sd, max_batch=1024)
+    xa = synth_vectors(cfg, sd, 4096, seed=71)
+    xb = synth_vectors(cfg, sd, 640, seed=72)
+    xc = synth_vectors(cfg, sd, 512, seed=73)
+    want_a = eng.encode(xa)                                # host path, alone
+    want_b = eng.encode(xb)
+    want_c = eng.encode(xc)
+    want_dec = eng.decode(want_b)
+    xa_d, xc_d = torch.from_numpy(xa).cuda(), torch.from_numpy(xc).cuda()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        got_a = eng.encode(xa_d)                           # asynchronous, four passes of max_batch
+        got_b = eng.encode(xb)                             # host path right behind it: private stream
+        got_dec = eng.decode(want_b)                       # host decode: the same scratch's decode side
+        got_a2 = eng.encode(xa_d)
+        with torch.cuda.stream(side):
+            got_c = eng.encode(xc_d)                       # another user stream while got_a2 is still running
+        torch.cuda.synchronize()
+        assert np.array_equal(got_a.cpu().numpy(), want_a) and np.array_equal(got_a2.cpu().numpy(), want_a)
+        assert np.array_equal(got_b, want_b) and np.array_equal(got_c.cpu().numpy(), want_c)
+        assert np.array_equal(got_dec.view(np.uint32), want_dec.view(np.uint32))
+    eng.close()

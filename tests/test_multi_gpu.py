@@ -135,6 +135,16 @@ def test_bench_self_launches_ranks_from_a_bare_python():
     assert len(mg["per_rank_encode_vectors_per_s"]) == 2 and all(v > 0 for v in mg["per_rank_encode_vectors_per_s"])
     assert len(mg["per_rank_gather_s"]) == 2 and mg["gather_bytes_per_rank"] == 2 * 512 * 8
     assert abs(rec["value"] - 2 * 2 * 512 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 1e-6
+    # the timed region is the product's path (encode_shard + gather_codes), and the line shows who ran where and what arrived
+    assert "gather_codes" in mg["path"] and mg["gathered_rows_verified_on_rank0"] is True
+    for r, info in enumerate(mg["per_rank"]):
+        assert info["rank"] == r and info["vectors"] == 1024 and info["gather_ok"] and info["rows_on_rank0_equal_to_the_shard"]
+        assert info["ranks_seen_by_payload_group"] == 2 and info["wire_dtype"] == "uint8" and info["encode_s"] > 0
+        assert info["bytes_sent"] == (0 if r == 0 else 1024 * 8) and info["bytes_received"] == (1024 * 8 if r == 0 else 0)
+        assert isinstance(info["gpu"], int) and "pci_bus_id" in info and "numa_node" in info
+    if backend == "nccl":
+        assert mg["rccl_ranks_seen"] == 2 and all(i["transport"] == "nccl" and i["buffers"] == "device" for i in mg["per_rank"])
+        assert len({i["gpu"] for i in mg["per_rank"]}) == 2 and len({i["pci_bus_id"] for i in mg["per_rank"]}) == 2
 
 
 def test_bench_strong_scaling_splits_one_database():
@@ -146,9 +156,29 @@ def test_bench_strong_scaling_splits_one_database():
                  "--scaling", "strong", "--db", "1636")
     assert rec["n_gpus"] == 3 and rec["scaling"] == "strong" and rec["config"]["distinct_vectors_encoded"] == 1636
     mg = rec["multi_gpu"]
-    assert mg["per_rank_vectors"] == [545, 545, 546] and mg["gather_ok_on_all_ranks"]
-    assert mg["gather_bytes_per_rank"] == 546 * 8
+    assert mg["per_rank_vectors"] == [545, 545, 546] and mg["gather_ok_on_all_ranks"] and mg["gathered_rows_verified_on_rank0"] is True
+    assert mg["gather_bytes_per_rank"] == 546 * 8 and [i["bytes_sent"] for i in mg["per_rank"]] == [0, 545 * 8, 546 * 8]
     assert abs(rec["value"] - 1636 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-6
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_dry_rccl_on_the_gpu_box(world):
+    """`bench.py --gpus N --dry-rccl`: the communication steps of the multi-GPU bench alone (payload group, a grouped 1-byte send /
+    recv with every peer, the product's gather_codes on a million fake rows, and -- on RCCL -- ncclCommInitRank through ctypes +
+    qinco_gather_codes).  With one GPU per rank this is RCCL over xGMI; on a 1-GPU box the ranks share GPU 0 and the payload rides
+    on gloo (host buffers): the same lines of bench.py and encode_db.py either way."""
+    import torch
+    rccl = torch.cuda.device_count() >= world
+    rec = _bench("--gpus", str(world), "--dry-rccl", "--backend", "nccl" if rccl else "gloo", "--rccl-timeout", "120")
+    assert rec["n_gpus"] == world and rec["all_ok"], rec
+    assert rec["rccl_ranks_seen"] == world and rec["rows"] == 1_000_000
+    want = {"communicator", "p2p_1_byte_with_every_peer", "gather_codes"} | ({"native_qinco_gather_codes"} if rccl else set())
+    assert set(rec["steps_ok_on_all_ranks"]) == want and all(rec["steps_ok_on_all_ranks"].values())
+    if rccl:
+        assert rec["nccl_comm_count"] == world
+        assert len({p["pci_bus_id"] for p in rec["per_rank"]}) == world
+        assert all(p["steps"]["gather_codes"]["transport"] == "nccl" and p["steps"]["gather_codes"]["buffers"] == "device" for p in rec["per_rank"])
+    assert sum(p["rows"] for p in rec["per_rank"]) == 1_000_000
 
 
 @pytest.mark.parametrize("mode", ["1", "hang"], ids=["raises", "hangs"])

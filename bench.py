@@ -360,7 +360,7 @@ def roofline_dict(prof, dt=None, kernel="qinco::mlp_kernel (+ its xproj pre-GEMM
 # ------------------------------------------------------------------------------------------------------------------
 # extra legs (N = 1, after the timed region)
 # ------------------------------------------------------------------------------------------------------------------
-def leg_workload(torch, dev, name, steps, batch, oracle_sample=0, decode_sizes=()):
+def leg_workload(torch, dev, name, steps, batch, oracle_sample=0, decode_sizes=(), split_compare=True):
     """One of BASELINE.json's other configurations at its bench batch: K distinct resident batches, timed like the headline,
     with the fused-MLP roofline.  oracle_sample > 0 (C1): that many vectors are also encoded by the oracle on the host --
     the count of identical code rows (the north_star's "bit-exact greedy codes") and the oracle's rate on the sample."""
@@ -401,6 +401,24 @@ def leg_workload(torch, dev, name, steps, batch, oracle_sample=0, decode_sizes=(
         for rows in decode_sizes:
             out[f"decode_batch_{rows}"] = leg_decode_calls(torch, dev, eng, cfg, codes_all, rows)
         del codes_all
+    if split_compare and not cfg.ivf:
+        # the opt-in split-fp16 form on the same timed batches (NOT part of `value`): rate, and the code rows it changes
+        try:
+            eng2 = QincoEngine(cfg, sd, max_batch=batch, split_f16=True)
+            eng2.encode(xs[0], code_dtype=cdt)
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            codes2 = [eng2.encode(xs[1 + s], code_dtype=cdt) for s in range(steps)]
+            torch.cuda.synchronize(dev)
+            dt2 = time.perf_counter() - t2
+            differ = int(sum(int((a != b).any(dim=1).sum().item()) for a, b in zip(codes, codes2)))
+            out["split_f16"] = {"value": steps * batch / dt2, "unit": "vectors/s", "speedup_vs_f32_path": (steps * batch / dt2) / out["value"],
+                                "rows_differing_from_f32_path": differ, "rows": steps * batch,
+                                "note": "opt-in QincoEngine(split_f16=True); fixture counts: parity.*.split_f16_codes_equal_to_reference"}
+            eng2.close()
+            del codes2
+        except Exception as e:                                # noqa: BLE001 -- no split instance for the shape
+            out["split_f16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if cfg.ivf:
         st = eng.ivf_last_stats()
         out["ivf"] = {"ivf_K": cfg.ivf_K, "exact_candidates_per_vector": st["candidates"] / batch, "fell_back_to_fp32_table": st["fell_back"],
@@ -413,13 +431,15 @@ def leg_workload(torch, dev, name, steps, batch, oracle_sample=0, decode_sizes=(
         got = codes[0][:oracle_sample].cpu().numpy().astype(np.int64)
         oracle(x[:16], step="encode")
         t1 = time.perf_counter()
-        want = oracle(x, step="encode").T
+        # (the reference's protocol: batches of cfg.batch = 1024, qinco_tasks.py:99-125; a 256-vector sample is one call)
+        want = np.concatenate([oracle(x[i:i + 1024], step="encode").T for i in range(0, len(x), 1024)])
         dt_o = time.perf_counter() - t1
         same = int((got == want).all(axis=1).sum())
         out["greedy_rows_equal_to_oracle"] = f"{same}/{oracle_sample}"
         out["cpu_baseline"] = {"value": oracle_sample / dt_o, "unit": "vectors/s", "cores": threads, "kind": "port",
                                "gflops": oracle_sample / dt_o * cfg.encode_flops_per_vector() / 1e9,
-                               "sample": f"the same {oracle_sample} vectors in one oracle call ({dt_o:.1f} s, {threads} ATen threads)"}
+                               "sample": f"the same {oracle_sample} vectors in oracle calls of <= 1024 ({dt_o:.1f} s, {threads} ATen threads; "
+                                         f"--c1-cpu-vectors 10000 = BASELINE.md section 3's protocol)"}
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     eng.close()
     del xs, codes
@@ -545,6 +565,13 @@ def parity_counts(torch, dev):
             out[key] = {"codes_equal_to_reference": f"{same}/{len(want)}",
                         "decode_max_rel_err": float(np.abs(dec - ref).max() / np.abs(ref).max()), "fixture": f"tests/golden/{name}.npz"}
             eng.close()
+            try:                                              # the opt-in split-fp16 form against the same reference codes
+                eng2 = QincoEngine(cfg, sd, max_batch=256, split_f16=True)
+                got2 = eng2.encode(torch.from_numpy(g["x"]).to(dev), code_dtype=np.int64).cpu().numpy()
+                out[key]["split_f16_codes_equal_to_reference"] = f"{int((got2 == want).all(axis=1).sum())}/{len(want)}"
+                eng2.close()
+            except Exception as e:                            # noqa: BLE001
+                out[key]["split_f16_codes_equal_to_reference"] = f"unavailable: {type(e).__name__}"
         except Exception as e:                                # noqa: BLE001 -- the headline must not depend on a fixture
             out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
     torch.cuda.empty_cache()
@@ -822,7 +849,7 @@ def main():
             extras(torch, dev, args, cfg, sd, eng, out, mine, batches, warm, value, sqerr_sum, QincoEngine)
         if world == 1 and not args.no_legs and not args.split_f16:
             out["parity"] = parity_counts(torch, dev)
-            for key, fn in (("c1", lambda: leg_workload(torch, dev, "C1", 3, 16384, oracle_sample=256, decode_sizes=(1024, 12288, 16384))),
+            for key, fn in (("c1", lambda: leg_workload(torch, dev, "C1", 3, 16384, oracle_sample=args.c1_cpu_vectors, decode_sizes=(1024, 12288, 16384))),
                             ("c3", lambda: leg_workload(torch, dev, "C3", 2, 16384)),
                             ("c4", lambda: leg_workload(torch, dev, "C4", 2, 16384)),
                             ("qinco2_S", lambda: leg_workload(torch, dev, "S", 6, 16384, decode_sizes=(1024, 12288, 16384))),

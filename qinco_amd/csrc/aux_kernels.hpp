@@ -12,6 +12,33 @@ __global__ void __launch_bounds__(64) selftest_sort_kernel(const unsigned* __res
   const int lane = threadIdx.x;
   out[(long)blockIdx.x * 64 + lane] = wave_sort64(in[(long)blockIdx.x * 64 + lane]);
 }
+// pair_top_t (select.hpp) on tiles of 32 rows x 256 distances given in memory: lane (j, half) loads row j in the MFMA C layout
+// (codeword 32 cb + 8 gq + 4 half + e -> register 16 cb + 4 gq + e).  coop != 0: the cooperative kernels' form -- 8 rows per wave, lanes
+// j >= 8 repeat them, 16 lists.
+__global__ void __launch_bounds__(64) selftest_pair_kernel(const float* __restrict__ d, int T, int* __restrict__ ids, int coop,
+                                                           int* __restrict__ rounds) {
+  __shared__ __attribute__((aligned(16))) unsigned lists[pair_lds_words<64>()];
+  const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
+  const int rows = coop ? 8 : 32;
+  const long row = (long)blockIdx.x * rows + (coop ? (j & 7) : j);
+  f32x16 acc[8];
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(d + row * 256 + cb * 32 + 8 * gq + 4 * half);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[cb][4 * gq + e] = t[e];
+    }
+  if (T == 0) {   // (self-test of the exchange itself: every lane reports what pair_partner hands it for its own lane number / a double of it)
+    ids[blockIdx.x * 128 + lane] = (int)pair_partner_u((unsigned)lane + 1000u, half);
+    ids[blockIdx.x * 128 + 64 + lane] = (int)pair_partner((double)lane * 0.5 + 7.0, half);
+    return;
+  }
+  if (coop) pair_top_t<8, 16>(acc, lane, T, lists, ids + row * T, j < 8, rounds + row);
+  else pair_top_t<8, 64>(acc, lane, T, lists, ids + row * T, true, rounds + row);
+}
+
 __global__ void __launch_bounds__(64) selftest_select_kernel(const float* __restrict__ d, int C, int T, int* __restrict__ ids,
                                                              int* __restrict__ fell_back) {
   extern __shared__ __attribute__((aligned(16))) float lds[];

@@ -17,11 +17,15 @@ hipError_t launch_small(const qinco::SmallArgs& a, hipStream_t st) {
     return hipErrorNotSupported;
   } else {
     auto kern = qinco::mlp_small_kernel<QD, QDE, QDH, NT, QF2 != 0, DEC>;
-    static bool raised = false;   // (per process and instantiation; the attribute is per function, setting it twice is harmless)
-    if (PL.lds_bytes > 64 * 1024 && !raised) {
+    // (per instantiation AND per device: the attribute applies to the current device's copy of the function, and a process may drive
+    // several GPUs; setting it twice is harmless, so the flags need no lock)
+    static bool raised[64] = {};
+    int devid = 0;
+    if (hipError_t e = hipGetDevice(&devid); e != hipSuccess) return e;
+    if (PL.lds_bytes > 64 * 1024 && !raised[devid & 63]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL.lds_bytes);
       if (e != hipSuccess) return e;
-      raised = true;
+      raised[devid & 63] = true;
     }
     const unsigned grid = (unsigned)((a.R + 16 * NT - 1) / (16 * NT));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * qinco::kSmallWaves), PL.lds_bytes, st, a);

@@ -2391,6 +2391,113 @@ extern "C" int qinco_selftest(void) {
                       hids[(size_t)p * T + t], order[t]);
     }
   }
+  // 3. pair_top_t: the lane-pair selection of the pre-selection table kernels, every T they can be asked for, both list layouts;
+  //    rows of continuous values, heavy / some / massive exact ties, NaN / inf / -0, constant rows, a row sorted the wrong way round
+  {
+    const int NT = 24, ROWS = NT * 32, K = 256;
+    std::vector<float> hd((size_t)ROWS * K);
+    for (int p = 0; p < ROWS; ++p)
+      for (int k = 0; k < K; ++k) {
+        float v;
+        const int kind = p % 8;
+        if (kind == 0 || kind == 5) v = (float)(rng.next() % 1000000) * 1e-4f - 20.f;     // continuous, both signs
+        else if (kind == 1) v = (float)(rng.next() % 40);                                  // heavy ties
+        else if (kind == 2) v = (float)(rng.next() % 1000) * 0.5f;                         // some ties
+        else if (kind == 3) {
+          const unsigned r = rng.next() % 50;
+          v = r == 0 ? __builtin_nanf("") : r == 1 ? __builtin_inff() : r == 2 ? -0.f : r == 3 ? -__builtin_inff() : (float)(rng.next() % 5000) * 1e-2f;
+        } else if (kind == 4) v = (p % 16 == 4) ? 3.25f : (k % 7 == 0 ? 1.f : 2.f);       // constant row / two values
+        else if (kind == 6) v = (float)(K - k) + (p % 3 == 0 ? 0.f : 1e-3f * (float)(rng.next() % 100));   // descending in k
+        else v = (rng.next() % 4 == 0) ? __builtin_nanf("") : (float)(rng.next() % 3);    // a quarter NaN, the rest from three values
+        hd[(size_t)p * K + k] = v;
+      }
+    float* dd = nullptr;
+    int* dids = nullptr;
+    HIP_TRY(hipMalloc(&dd, hd.size() * 4));
+    HIP_TRY(hipMalloc(&dids, (size_t)ROWS * 64 * 4));
+    HIP_TRY(hipMemcpy(dd, hd.data(), hd.size() * 4, hipMemcpyHostToDevice));
+    std::vector<std::vector<int>> order(ROWS, std::vector<int>(K));
+    for (int p = 0; p < ROWS; ++p) {
+      const float* row = &hd[(size_t)p * K];
+      auto key = [&](int k) -> unsigned long long {   // NaN last, -0 == +0, ties -> lower index
+        const float v = row[k];
+        unsigned u;
+        if (v != v) u = 0xffffffffu;
+        else {
+          const float z = v + 0.f;
+          std::memcpy(&u, &z, 4);
+          u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        }
+        return ((unsigned long long)u << 32) | (unsigned)k;
+      };
+      for (int k = 0; k < K; ++k) order[p][k] = k;
+      std::sort(order[p].begin(), order[p].end(), [&](int x, int y) { return key(x) < key(y); });
+    }
+    const int Ts[] = {16, 8, 32, 1, 2, 3, 4, 12, 15, 17, 24, 31, 33, 64};
+    std::vector<int> hids((size_t)ROWS * 64), hrounds(ROWS);
+    int* drounds = nullptr;
+    HIP_TRY(hipMalloc(&drounds, ROWS * 4));
+    {   // the exchange with lane ^ 32 itself (v_permlane32_swap): 32-bit and 64-bit
+      hipLaunchKernelGGL(selftest_pair_kernel, dim3(1), dim3(64), 0, nullptr, dd, 0, dids, 0, drounds);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpy(hids.data(), dids, 128 * 4, hipMemcpyDeviceToHost));
+      for (int l = 0; l < 64; ++l)
+        if (hids[l] != (l ^ 32) + 1000 || hids[64 + l] != (int)((double)(l ^ 32) * 0.5 + 7.0)) {
+          (void)hipFree(dd);
+          (void)hipFree(dids);
+          (void)hipFree(drounds);
+          return fail(QINCO_ERR_HIP, "qinco_selftest: pair_partner hands lane %d the values %d / %d (want %d / %d)", l, hids[l], hids[64 + l],
+                      (l ^ 32) + 1000, (int)((double)(l ^ 32) * 0.5 + 7.0));
+        }
+    }
+    for (int coop = 0; coop < 2; ++coop)
+      for (int T : Ts) {
+        HIP_TRY(hipMemset(dids, 0xFF, (size_t)ROWS * T * 4));
+        HIP_TRY(hipMemset(drounds, 0, ROWS * 4));
+        hipLaunchKernelGGL(selftest_pair_kernel, dim3(coop ? ROWS / 8 : NT), dim3(64), 0, nullptr, dd, T, dids, coop, drounds);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(hids.data(), dids, (size_t)ROWS * T * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hrounds.data(), drounds, ROWS * 4, hipMemcpyDeviceToHost));
+        // the fast path must be what runs on continuous data (kinds 0 and 5) for 2 <= T <= 16: a selection that silently went to
+        // the exact rounds every time would pass every parity test at a tenth of the speed
+        if (T >= 2 && T <= 16) {
+          int went = 0, rows = 0;
+          for (int p = 0; p < ROWS; ++p)
+            if (p % 8 == 0 || p % 8 == 5) {
+              ++rows;
+              went += (hrounds[p] & 3) != 0;
+            }
+          if (went * 50 > rows) {
+            (void)hipFree(dd);
+            (void)hipFree(dids);
+            (void)hipFree(drounds);
+            return fail(QINCO_ERR_HIP, "qinco_selftest: pair_top_t sent %d of %d continuous rows to the rounds (T=%d, coop=%d)", went, rows, T, coop);
+          }
+        }
+        for (int p = 0; p < ROWS; ++p)
+          for (int t = 0; t < T; ++t)
+            if (hids[(size_t)p * T + t] != order[p][t]) {
+              (void)hipFree(dd);
+              (void)hipFree(dids);
+              return fail(QINCO_ERR_HIP, "qinco_selftest: pair_top_t wrong (T=%d, coop=%d, row %d of kind %d, rank %d: %d, want %d)", T, coop, p,
+                          p % 8, t, hids[(size_t)p * T + t], order[p][t]);
+            }
+      }
+    (void)hipFree(dd);
+    (void)hipFree(dids);
+    (void)hipFree(drounds);
+  }
+  return QINCO_OK;
+}
+
+// Diagnostics (scripts/exp_pair_select.py; not part of include/qinco_hip.h): the lane-pair selection alone on `rows` (a multiple of 32)
+// rows of 256 distances in device memory -> ids (rows, T), rounds (rows): 1 where a row went to the exact arg-min rounds.
+extern "C" __attribute__((visibility("default"))) int qinco_debug_pair_select(const float* d, long rows, int T, int coop, int* ids,
+                                                                               int* rounds, void* stream) {
+  if (!d || !ids || !rounds || rows <= 0 || rows % 32 || T < 1 || T > 64) return fail(QINCO_ERR_INVALID, "qinco_debug_pair_select: bad argument");
+  hipLaunchKernelGGL(selftest_pair_kernel, dim3((unsigned)(coop ? rows / 8 : rows / 32)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), d, T,
+                     ids, coop, rounds);
+  HIP_TRY(hipGetLastError());
   return QINCO_OK;
 }
 

@@ -192,10 +192,15 @@ extern "C" int qinco_rerank(const float* xq, const float* cand, int64_t nq, int3
   while (P < ns) P <<= 1;
   const size_t lds = (size_t)P * 8 + (size_t)D * 4;
   if (lds > 160 * 1024) return fail(QINCO_ERR_UNSUPPORTED, "qinco_rerank: a shortlist of %d rows of %d features does not fit the 160 KiB of LDS", ns, D);
-  static size_t raised = 0;
-  if (lds > 64 * 1024 && lds > raised) {
+  // (the attribute applies to the CURRENT device's copy of the function: the high-water mark is kept per device -- a process that
+  // drives a second GPU has to raise the limit there too)
+  static size_t raised[64] = {};
+  int devid = 0;
+  HIP_TRY(hipGetDevice(&devid));
+  size_t& mark = raised[devid & 63];
+  if (lds > 64 * 1024 && lds > mark) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rerank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    raised = lds;
+    mark = lds;
   }
   RerankArgs a{xq, cand, (long)nq, ns, D, k, P, reinterpret_cast<const long long*>(ids_in), codes_in, Mc,
                reinterpret_cast<long long*>(pos_out), dist_out, reinterpret_cast<long long*>(ids_out), codes_out};

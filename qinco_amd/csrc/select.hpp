@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
+#include "mlp_args.hpp"
 
 namespace qinco {
 
@@ -213,6 +215,268 @@ QINCO_DEV void wave_top_t(float* dv, int C, int T, unsigned long long* surv, int
     }
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lane-pair selection (round 5): the T smallest of a group's K = 256 distances while they still sit in the MFMA's C layout.
+//
+// A 32 x 256 table tile of a wave leaves the matrix pipe with lane (j, half) holding 128 of group j's distances (codeword
+// k = 32 cb + 8 gq + 4 half + e in register 16 cb + 4 gq + e).  The wave-wide selection above takes ONE group at a time across the
+// 64 lanes (sort of the lane minima, ballot / mbcnt compaction, rank by counting: ~240 VALU instructions per group, 7.6 k per tile --
+// as long as the tile's 512 MFMAs; counters in profiles/r04_S_khead_pmc_*).  Here every lane pair (l, l ^ 32) works on ITS group and
+// all 32 groups advance with every instruction, no cross-lane step except the exchange with the partner:
+//   1. threshold: per lane 32 quad minima, its 16 smallest sorted in registers (two 63-comparator networks + a merge); with the
+//      partner's the T-th smallest of the group's 64 quad minima tau bounds its T-th smallest distance from above (T quads hold an
+//      element <= tau); T <= 16;
+//   2. survivors: one pass over the 128 registers, "always write, advance when it survives": (distance bits, codeword) go to the
+//      lane's list in LDS ([entry][lane]: conflict-free), ~18 survivors per group for T = 16;
+//   3. order: the group's survivors -- lane 0's list, then lane 1's -- as 32 keys, 16 per lane, sorted by the same network and one
+//      bitonic merge across the pair.  A key is a DOUBLE in [1, 2) whose mantissa is (ordered distance bits << 8 | codeword): doubles of
+//      one binade order like their mantissas, so a compare-exchange is v_min_f64 + v_max_f64 instead of a 64-bit compare and four
+//      selects.  Exactly the lexicographic (distance, index) order (ties -> lower index: argmin / stable argsort,
+//      qinco_inference.py:173,200; -0.0 == +0.0).
+// ~2.1 k VALU instructions per 32 groups.  Exactness does not depend on step 1: the survivors are {d <= tau}, so whenever a group has
+// S >= T of them they contain its T smallest, ties included; a group with S < T (NaN / infinite distances in the minima) or with more
+// survivors than the lists hold (massive exact ties) is redone -- with T == 1 and T > 32 -- by rounds of exact arg-min over the
+// registers (pair_rounds: slow, always right, NaN last).
+// ---------------------------------------------------------------------------------------------
+constexpr int PAIR_LIST = 24;                   // survivors a lane can hold (one more entry absorbs the writes past the end)
+constexpr int PAIR_GROUP_MAX = 32;              // survivors of a group the sort takes
+constexpr int PAIR_T_MAX = 16;                  // largest T of the fast path: for T = 17 .. 32 a threshold from 32 bucket minima leaves ~100 survivors
+constexpr unsigned PAIR_SENTINEL = 0x7fffffffu; // distance bits of an empty list entry (a positive NaN: never a survivor's)
+// unsigned of LDS per wave: [entry][list][distance bits, codeword] with NL lists -- one per lane (64), or 16 when only lanes
+// j < 8 of each half own a group (the cooperative small-launch kernels: the other lanes repeat them and write the same values)
+template <int NL>
+constexpr int pair_lds_words() { return (PAIR_LIST + 1) * NL * 2; }
+
+constexpr int kSort16[63][2] = {
+    {0, 1},   {2, 3},   {4, 5},   {6, 7},   {8, 9},   {10, 11}, {12, 13}, {14, 15}, {0, 2},   {1, 3},   {4, 6},   {5, 7},   {8, 10},
+    {9, 11},  {12, 14}, {13, 15}, {1, 2},   {5, 6},   {9, 10},  {13, 14}, {0, 4},   {1, 5},   {2, 6},   {3, 7},   {8, 12},  {9, 13},
+    {10, 14}, {11, 15}, {2, 4},   {3, 5},   {10, 12}, {11, 13}, {1, 2},   {3, 4},   {5, 6},   {9, 10},  {11, 12}, {13, 14}, {0, 8},
+    {1, 9},   {2, 10},  {3, 11},  {4, 12},  {5, 13},  {6, 14},  {7, 15},  {4, 8},   {5, 9},   {6, 10},  {7, 11},  {2, 4},   {3, 5},
+    {6, 8},   {7, 9},   {10, 12}, {11, 13}, {1, 2},   {3, 4},   {5, 6},   {7, 8},   {9, 10},  {11, 12}, {13, 14}};   // Batcher, 0-1 checked
+constexpr int kMerge16[32][2] = {{0, 8},  {1, 9},  {2, 10}, {3, 11},  {4, 12},  {5, 13},  {6, 14},  {7, 15},  {0, 4},   {1, 5},   {2, 6},
+                                 {3, 7},  {8, 12}, {9, 13}, {10, 14}, {11, 15}, {0, 2},   {1, 3},   {4, 6},   {5, 7},   {8, 10},  {9, 11},
+                                 {12, 14}, {13, 15}, {0, 1}, {2, 3},  {4, 5},   {6, 7},   {8, 9},   {10, 11}, {12, 13}, {14, 15}};   // bitonic -> ascending
+
+template <class F, int... Is>
+QINCO_DEV void sel_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f.template operator()<Is>(), ...);
+}
+template <int N, class F>
+QINCO_DEV void sel_static_for(F&& f) {
+  sel_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// v_min / v_max as the instructions themselves: __builtin_fminf is llvm.minnum, in front of which hipcc canonicalises every operand it
+// cannot prove quiet (a v_max_f32 x, x per MFMA result: 128 + 80 extra instructions here).  A signalling NaN cannot reach these: the
+// distances are results of VALU arithmetic, the keys are constructed.  (Plain asm, not volatile: free to schedule.)
+QINCO_DEV float pair_min(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+QINCO_DEV float pair_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+QINCO_DEV float pair_min3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+QINCO_DEV double pair_min(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+QINCO_DEV double pair_max(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// compare-exchange: v_min + v_max (f32 or f64)
+template <class V>
+QINCO_DEV void pair_cex(V& a, V& b) {
+  const V lo = pair_min(a, b), hi = pair_max(a, b);
+  a = lo;
+  b = hi;
+}
+template <class V>
+QINCO_DEV void pair_sort16(V (&v)[16]) {
+  sel_static_for<63>([&]<int i>() __attribute__((always_inline)) { pair_cex(v[kSort16[i][0]], v[kSort16[i][1]]); });
+}
+template <class V>
+QINCO_DEV void pair_merge16(V (&v)[16]) {
+  sel_static_for<32>([&]<int i>() __attribute__((always_inline)) { pair_cex(v[kMerge16[i][0]], v[kMerge16[i][1]]); });
+}
+// the value lane l ^ 32 holds (v_permlane32_swap: the upper half of vdst trades places with the lower half of src)
+QINCO_DEV unsigned pair_partner_u(unsigned v, int half) {
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return half ? (unsigned)r[0] : (unsigned)r[1];
+}
+QINCO_DEV float pair_partner(float v, int half) { return __builtin_bit_cast(float, pair_partner_u(__builtin_bit_cast(unsigned, v), half)); }
+QINCO_DEV double pair_partner(double v, int half) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = pair_partner_u((unsigned)u, half), hi = pair_partner_u((unsigned)(u >> 32), half);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// codeword of register slot r of a lane (MFMA 32x32 C layout, see above)
+constexpr unsigned pair_slot_codeword(int r) { return (unsigned)(((r >> 4) << 5) | (((r >> 2) & 3) << 3) | (r & 3)); }
+QINCO_DEV double pair_key(unsigned dbits, unsigned k) {
+  const unsigned key = dbits == PAIR_SENTINEL ? 0xffffffffu : ordered_bits(__builtin_bit_cast(float, dbits));
+  return __builtin_bit_cast(double, ((unsigned long long)(0x3ff00000u | (key >> 24)) << 32) | (unsigned long long)((key << 8) | k));
+}
+
+// Exact rounds: rank t = the smallest (distance key, codeword) above rank t - 1, found over the registers of both lanes.
+template <int NKB>
+QINCO_DEV void pair_rounds(const f32x16 (&acc)[NKB], int half, int T, bool mine, int* __restrict__ out) {
+  const unsigned kh = (unsigned)half << 2;
+  unsigned long long prev = 0;
+  for (int t = 0; t < T; ++t) {
+    unsigned long long best = ~0ull;
+#pragma unroll
+    for (int r = 0; r < NKB * 16; ++r) {
+      const unsigned long long key = ((unsigned long long)sel_key(acc[r >> 4][r & 15]) << 32) | (pair_slot_codeword(r) | kh);
+      const bool take = (t == 0 || key > prev) && key < best;
+      best = take ? key : best;
+    }
+    const unsigned plo = pair_partner_u((unsigned)best, half), phi = pair_partner_u((unsigned)(best >> 32), half);
+    const unsigned long long pb = ((unsigned long long)phi << 32) | plo;
+    best = pb < best ? pb : best;
+    if (mine && half == 0) out[t] = best == ~0ull ? 0 : (int)(unsigned)best;   // (only NaNs left and T > their number: degenerate, keep in range)
+    prev = best;
+  }
+}
+
+// acc: the lane's 16 NKB distances; lists: pair_lds_words<NL>() unsigned of LDS private to this wave; out: ids_out + group * T
+// (written when store).  All 64 lanes must be active; lanes whose group is a copy (past the end of the launch) pass store = false.
+template <int NKB, int NL = 64>
+QINCO_DEV void pair_top_t(const f32x16 (&acc)[NKB], int lane, int T, unsigned* lists, int* __restrict__ out, bool store,
+                          int* __restrict__ went_to_rounds = nullptr) {
+  static_assert(NKB == 8, "16 buckets of 8 registers per lane: K = 256");
+  static_assert(NL == 64 || NL == 16, "");
+  constexpr int ES = NL * 2;                                                       // words per entry row
+  const int half = lane >> 5;
+  const int li = NL == 64 ? lane : ((lane & 7) | (half << 3));                     // this lane's list
+  bool redo = true;   // this lane's group still has to go through the rounds
+  int dbg_S = 0;
+  if (T >= 2 && T <= PAIR_T_MAX) {   // (wave-uniform)
+    // ---- 1. tau: the T-th smallest of the group's 64 quad minima (a quad = the four registers e = 0 .. 3 of a (cb, gq)).  Only a
+    // lane's 16 smallest minima can matter: two sorted halves of 16, the lower 16 of their union (bitonic), sorted.
+    // (Round 5's first version used 32 buckets of 8: ~21 survivors for T = 16 and one group in 2500 above the 32 the sort takes --
+    // and ONE such group in a launch sends its wave through 16 exact rounds, ~50 us during which the rest of the chip idles:
+    // 102 -> 170 us per launch.  With 64 buckets of 4: 17.6 survivors on average, 28 at most in 4 x 10^5 random groups.)
+    float m[16];
+    {
+      float qa[16], qb[16];
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const f32x16& lo = acc[b >> 2];
+        const f32x16& hi = acc[4 + (b >> 2)];
+        const int o = (b & 3) * 4;
+        qa[b] = pair_min(pair_min3(lo[o], lo[o + 1], lo[o + 2]), lo[o + 3]);
+        qb[b] = pair_min(pair_min3(hi[o], hi[o + 1], hi[o + 2]), hi[o + 3]);
+      }
+      pair_sort16(qa);
+      pair_sort16(qb);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m[i] = pair_min(qa[i], qb[15 - i]);
+    }
+    pair_merge16(m);
+    float z[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = pair_min(m[i], pair_partner(m[15 - i], half));   // the 16 smaller of the two sorted lists: bitonic
+    pair_merge16(z);
+    float tau = z[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) tau = ((T - 1) & 15) == i ? z[i] : tau;
+    // ---- 2. survivors {d <= tau} -> this lane's list, in register order
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    lds_u32* const mylist = (lds_u32*)lists + li * 2;   // entry e at mylist[e * ES + {0, 1}]  (32-bit LDS pointers: no address arithmetic per store)
+#pragma unroll
+    for (int e = 0; e <= PAIR_LIST; ++e) mylist[e * ES] = PAIR_SENTINEL;
+    const unsigned kh = (unsigned)half << 2;
+    lds_u32* cur = mylist;
+    lds_u32* const lim = mylist + PAIR_LIST * ES;   // entry PAIR_LIST absorbs an over-long list
+#pragma unroll
+    for (int r = 0; r < NKB * 16; ++r) {
+      const float d = acc[r >> 4][r & 15];
+#if defined(QINCO_EXPERIMENT) && QINCO_PAIR_EXP == 1   // timing only (wrong results): every write goes to entry 0
+      mylist[0] = __builtin_bit_cast(unsigned, d);
+      mylist[1] = pair_slot_codeword(r) | kh;
+#else
+      cur[0] = __builtin_bit_cast(unsigned, d);
+      cur[1] = pair_slot_codeword(r) | kh;
+#endif
+      lds_u32* const nxt = cur + (d <= tau ? ES : 0);
+      cur = nxt < lim ? nxt : lim;
+    }
+    cur[0] = PAIR_SENTINEL;                      // the entry behind the last survivor holds the last register's distance
+    const int cnt = (int)((cur - mylist) / ES);
+    const int cnt_p = (int)pair_partner_u((unsigned)cnt, half);
+    const int cnt0 = half ? cnt_p : cnt, S = cnt + cnt_p;
+    const bool ok = cnt < PAIR_LIST && cnt_p < PAIR_LIST && S >= T && S <= PAIR_GROUP_MAX;
+    __builtin_amdgcn_wave_barrier();
+    // ---- 3. the group's survivors (lane 0's, then lane 1's; sentinels behind them), 16 per lane, sorted
+    double key[16];
+    const unsigned* const list0 = lists + (li & (NL / 2 - 1)) * 2;
+    const unsigned* const list1 = lists + (li | (NL / 2)) * 2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = 16 * half + i;                                  // position in the group's list
+      const bool second = p >= cnt0;
+      int e = second ? p - cnt0 : p;
+      e = e < PAIR_LIST ? e : PAIR_LIST;                            // (behind both lists: a sentinel entry)
+      const unsigned* src = (second ? list1 : list0) + e * ES;
+      const unsigned long long both = *reinterpret_cast<const unsigned long long*>(src);
+      // (lane 0's entries behind its last survivor are sentinels too, but the group's list continues with lane 1's: p >= cnt0 reads there)
+      key[i] = pair_key((unsigned)both, (unsigned)(both >> 32));
+    }
+    __builtin_amdgcn_wave_barrier();
+    pair_sort16(key);
+    double w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = pair_partner(key[15 - i], half);   // (the exchange needs both lanes of the pair: not under the branch)
+    if (half == 0) {   // lane 0 keeps the 16 smaller of the 32, lane 1 the 16 larger: bitonic sequences
+#pragma unroll
+      for (int i = 0; i < 16; ++i) w[i] = pair_min(key[i], w[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) w[i] = pair_max(key[i], w[i]);
+    }
+    pair_merge16(w);
+    if (ok && store) {   // lane `half` holds ranks 16 half .. 16 half + 15
+      int* o = out + 16 * half;
+      if ((T & 3) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (16 * half + 4 * q < T) {
+            int4 v;
+            v.x = (int)((unsigned)__builtin_bit_cast(unsigned long long, w[4 * q]) & 0xffu);
+            v.y = (int)((unsigned)__builtin_bit_cast(unsigned long long, w[4 * q + 1]) & 0xffu);
+            v.z = (int)((unsigned)__builtin_bit_cast(unsigned long long, w[4 * q + 2]) & 0xffu);
+            v.w = (int)((unsigned)__builtin_bit_cast(unsigned long long, w[4 * q + 3]) & 0xffu);
+            *reinterpret_cast<int4*>(o + 4 * q) = v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (16 * half + i < T) o[i] = (int)((unsigned)__builtin_bit_cast(unsigned long long, w[i]) & 0xffu);
+      }
+    }
+    redo = !ok;
+    dbg_S = S;
+  }
+  // (the self-test's view, qinco_selftest / scripts/exp_pair_select.py: bit `half` = this lane sends the group to the rounds, byte
+  // 1 + half = the survivors it counted)
+  if (went_to_rounds && store) atomicOr(went_to_rounds, (redo ? 1 << half : 0) | ((dbg_S & 255) << (8 + 8 * half)));
+  // the pair's lanes agree on `redo` (both computed S); a wave without such a group skips the rounds
+#if defined(QINCO_EXPERIMENT) && QINCO_PAIR_EXP == 2   // timing only: no rounds behind the fast path
+  if (T >= 2 && T <= PAIR_T_MAX) return;
+#endif
+  if (__builtin_amdgcn_ballot_w64(redo) != 0) pair_rounds<NKB>(acc, half, T, redo && store, out);
 }
 
 // wave_sort64 of GP independent values, one compare-exchange step at a time across all of them (a dependent DPP chain needs

@@ -14,12 +14,13 @@ namespace qinco {
 // K1+K2 on the matrix cores: the residual -> codebook table of dist_topk_kernel (aux_kernels.hpp) for K = 32*NKB
 // codewords, evaluated like the IVF table (a wave = 32 groups as B operands, codebook fragments as A operands), then the
 // T smallest per group, ascending.  r = x - xhat is formed on load (blocks are streamed, so any D fits), |r|^2 on the fly.
-// The 32 x K tile of a wave goes through a wave-private LDS table in two halves of 16 groups ([16][K + 4] floats): 66.5 KiB
-// per workgroup and <= 256 registers, so that TWO workgroups share a CU -- the table phase (matrix pipe) and the selection
-// phase (VALU / LDS / SALU latency chains) of a wave do not overlap with themselves, only with another wave's.
-// Selection: threshold-and-compact (select.hpp, wave_select_smallest_multi), four groups side by side; T = 1 and
-// T > 64 take rounds of wave arg-min.
-// (history: VALU table 621 us per 65 536 groups -> MFMA table + T arg-min rounds 235 us -> this form, profiles/r02_*)
+// <= 256 registers and 50 KiB of LDS, so that TWO workgroups share a CU: the table phase (matrix pipe) and the selection phase (VALU)
+// of a wave do not overlap with themselves, only with another wave's.
+// Selection (round 5): in the registers the MFMA left the distances in -- every lane pair selects its own group, all 32 groups of the
+// tile at once (select.hpp pair_top_t: bucket-minimum threshold, one compaction pass, a 32-key sort on v_min_f64 / v_max_f64); T = 1,
+// T > 32 and degenerate groups take exact arg-min rounds over the registers.
+// (history: VALU table 621 us per 65 536 groups -> MFMA table + T arg-min rounds 235 us -> table through LDS + wave-wide
+// threshold-and-compact per group 142 us per 131 072 (rounds 2-4, ~240 VALU instructions per group) -> this form)
 // ---------------------------------------------------------------------------------------------
 template <int D, int NKB>
 __global__ void __launch_bounds__(256, 2)
@@ -28,9 +29,8 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
                       int* __restrict__ ids_out, int gpw) {
   // gpw = groups per wave (32, or 8 for small launches, which could not fill the chip with 32-group waves; lanes past gpw
   // repeat the last group in the MFMA tile and are not selected)
-  constexpr int NDB = D / 32, K = NKB * 32, LDK = K + 4, SGP = 4;
-  __shared__ __attribute__((aligned(16))) float table[4 * 16 * LDK];
-  __shared__ unsigned long long surv_all[4 * SGP * SEL_SURV];
+  constexpr int NDB = D / 32;
+  __shared__ __attribute__((aligned(16))) unsigned pair_lists[4 * pair_lds_words<64>()];   // 12.5 KiB per wave: the survivors' lists
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
   const long g0 = ((long)blockIdx.x * 4 + wave) * gpw;
@@ -109,92 +109,9 @@ dist_topk_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xha
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[cb][4 * gq + e] = __fsub_rn(__fadd_rn(rn, cn[e]), __fmul_rn(2.f, acc[cb][4 * gq + e]));
     }
-  float* mytab = table + wave * 16 * LDK;
-  unsigned long long* surv = surv_all + wave * SGP * SEL_SURV;
+  // selection in the layout the matrix pipe left the distances in: the lane pair (j, j + 32) owns group j (select.hpp pair_top_t)
   const int gend = (int)((G - g0) < gpw ? (G - g0) : gpw);
-  for (int h = 0; h < 2 && h * 16 < gend; ++h) {
-    // groups h*16 .. h*16+15 of the tile -> table rows 0..15
-    if ((j >> 4) == h) {
-      float* row = mytab + (j & 15) * LDK;
-#pragma unroll
-      for (int cb = 0; cb < NKB; ++cb)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const f32x4 d = {acc[cb][4 * gq], acc[cb][4 * gq + 1], acc[cb][4 * gq + 2], acc[cb][4 * gq + 3]};
-          *reinterpret_cast<f32x4*>(row + cb * 32 + 8 * gq + 4 * half) = d;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int nrow = gend - h * 16 < 16 ? gend - h * 16 : 16;
-    const long gbase = g0 + h * 16;
-    if (T > 1 && T <= 64) {
-      for (int r0 = 0; r0 < nrow; r0 += SGP) {
-        // (rows past nrow hold stale distances of this wave: selected and discarded)
-        int rank[SGP], index[SGP];
-        const unsigned ok = wave_select_smallest_multi<SGP, K / 64>(mytab + r0 * LDK, LDK, T, surv, lane, rank, index);
-#pragma unroll
-        for (int u = 0; u < SGP; ++u) {
-          const int r = r0 + u;
-          if (r >= nrow) break;
-          if ((ok >> u) & 1) {
-            if (rank[u] >= 0) ids_out[(gbase + r) * T + rank[u]] = index[u];
-            continue;
-          }
-          float* dg = mytab + r * LDK;   // massive exact ties: the arg-min rounds
-          for (int t = 0; t < T; ++t) {
-            float bv = __builtin_inff();
-            int bi = 0x7fffffff;
-#pragma unroll
-            for (int k = lane; k < K; k += 64) {
-              const float v = dg[k];
-              const bool take = v < bv;
-              bv = take ? v : bv;
-              bi = take ? k : bi;
-            }
-            wave_argmin(bv, bi);
-            if (bi == 0x7fffffff) bi = 0;
-            if (lane == 0) ids_out[(gbase + r) * T + t] = bi;
-            if ((bi & 63) == lane) dg[bi] = __builtin_inff();
-            __builtin_amdgcn_wave_barrier();
-          }
-        }
-      }
-    } else {
-      // T == 1 (arg-min: step 0 of a greedy search) or T > 64: rounds of wave arg-min.  The rounds of one group are a chain
-      // of dependent cross-lane shuffles (latency-bound), so GP groups are reduced side by side.
-      constexpr int GP = 8;
-      for (int r0 = 0; r0 < nrow; r0 += GP) {
-        for (int t = 0; t < T; ++t) {
-          float bv[GP];
-          int bi[GP];
-#pragma unroll
-          for (int u = 0; u < GP; ++u) {
-            const float* dg = mytab + (r0 + u < 16 ? r0 + u : 15) * LDK;
-            bv[u] = __builtin_inff();
-            bi[u] = 0x7fffffff;
-#pragma unroll
-            for (int k = lane; k < K; k += 64) {  // k ascends: strict < keeps the lowest index
-              const float v = dg[k];
-              const bool take = v < bv[u];
-              bv[u] = take ? v : bv[u];
-              bi[u] = take ? k : bi[u];
-            }
-          }
-          wave_argmin_u<GP>(bv, bi);  // GP interleaved integer-min chains: no branch, no SGPR round trip
-#pragma unroll
-          for (int u = 0; u < GP; ++u) {
-            if (r0 + u < nrow) {
-              int b = bi[u] == 0x7fffffff ? 0 : bi[u];
-              if (lane == 0) ids_out[(gbase + r0 + u) * T + t] = b;
-              if ((b & 63) == lane) mytab[(r0 + u) * LDK + b] = __builtin_inff();
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();   // the next half overwrites the rows
-  }
+  pair_top_t<NKB>(acc, lane, T, pair_lists + wave * pair_lds_words<64>(), ids_out + (g0 + j) * (long)T, j < gend);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -269,6 +186,8 @@ dist_topk_mfma_coop_kernel(const float* __restrict__ x, const float* __restrict_
     }
   }
   __syncthreads();
+  // (one wave per SIMD here and 8 groups per wave: the WAVE-wide selection, four groups side by side -- 64 lanes per group, ~9 k cycles
+  // for the 8 -- beats the lane-pair form of the large-launch kernel, which would run 16 of its 64 lanes for ~18 k: measured, round 5)
   coop_select_rows<K, LDK, SGP>(table, surv_all + wave * SGP * SEL_SURV, lane, wave, g0, G, T, ids_out);
 }
 

@@ -12,7 +12,7 @@ from qinco_amd import QincoEngine, synth_state_dict, synth_vectors  # noqa: E402
 from qinco_amd.config import preset  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-for A in (1, 2, 8, 16, 32):
+for A in ([int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 8, 16, 32)):
     cfg = preset("qinco2-S", D=128, M=3, A=A, B=8)
     sd = synth_state_dict(cfg, 5)
     eng = QincoEngine(cfg, sd, max_batch=n)

@@ -1,16 +1,16 @@
 #!/bin/bash
 # One rocprofv3 --pmc pass per bench leg: the MFMA FLOPs the hardware counted (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512) against the count the
 # library reports for the same calls (qinco_profile_read2, bench.py's roofline.frac).  usage: gpu_pmc_legs.sh "<workload> <mode> <rows>" ...
-# -> gpurun_out/r04_pmc_<wl>_<mode>_<rows>_counters.csv + one summary line per leg in gpurun_out/r04_pmc_legs.jsonl
+# -> gpurun_out/<round>_pmc_<wl>_<mode>_<rows>_counters.csv + one summary line per leg in gpurun_out/${ROUND:-r05}_pmc_legs.jsonl
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 cd /tmp
-: > $O/r04_pmc_legs.jsonl
+: > $O/${ROUND:-r05}_pmc_legs.jsonl
 for cfg in "$@"; do
   set -- $cfg
-  n=r04_pmc_$1_$2_$3
+  n=${ROUND:-r05}_pmc_$1_$2_$3
   timeout 900 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/prof_$n -o t -- python $R/scripts/prof_calls.py $1 $2 $3 4 > $O/$n.log 2>&1
   db=$(find $O/prof_$n -name '*.db' | head -1); python $R/scripts/rocpd_summary.py $db $O/$n; rm -rf $O/prof_$n
-  python - $O/${n}_counters.csv $O/$n.log "$cfg" >> $O/r04_pmc_legs.jsonl <<PY
+  python - $O/${n}_counters.csv $O/$n.log "$cfg" >> $O/${ROUND:-r05}_pmc_legs.jsonl <<PY
 import csv, json, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 lib = [json.loads(l[8:]) for l in open(sys.argv[2]) if l.startswith("LIBRARY ")][0]
@@ -23,5 +23,5 @@ print(json.dumps({"leg": sys.argv[3], "pmc_mfma_flops_per_call": pmc_flops_per_c
                   "algorithmic_flops_per_call": lib["algorithmic_flops_per_call"], "dominant_kernel": top["kernel"][:80],
                   "dominant_kernel_avg_us_under_pmc": float(top["avg_us"])}))
 PY
-  tail -1 $O/r04_pmc_legs.jsonl
+  tail -1 $O/${ROUND:-r05}_pmc_legs.jsonl
 done

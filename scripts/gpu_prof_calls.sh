@@ -1,10 +1,10 @@
 #!/bin/bash
-# rocprofv3 kernel trace of small calls: gpu_prof_calls.sh "<workload> <mode> <rows>" ...  -> gpurun_out/r04_<wl>_<mode>_<rows>_{kernel_stats,by_grid}.csv
+# rocprofv3 kernel trace of small calls: gpu_prof_calls.sh "<workload> <mode> <rows>" ...  -> gpurun_out/<round>_<wl>_<mode>_<rows>_{kernel_stats,by_grid}.csv
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 cd /tmp
 for cfg in "$@"; do
   set -- $cfg
-  n=r04_$1_$2_$3
+  n=${ROUND:-r05}_$1_$2_$3
   timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$n -o t -- python $R/scripts/prof_calls.py $1 $2 $3 20 > $O/$n.log 2>&1
   db=$(find $O/prof_$n -name '*.db' | head -1); python $R/scripts/rocpd_summary.py $db $O/$n; rm -rf $O/prof_$n
   echo "=== $cfg"; grep "vectors/s" $O/$n.log

@@ -1262,3 +1262,48 @@ def test_host_calls_are_ordered_behind_device_calls_on_the_same_engine():
         assert np.array_equal(got_b, want_b) and np.array_equal(got_c.cpu().numpy(), want_c)
         assert np.array_equal(got_dec.view(np.uint32), want_dec.view(np.uint32))
     eng.close()
+
+
+@pytest.mark.parametrize("D,de,dh", [(64, 96, 160), (100, 128, 256), (200, None, 300), (384, 128, 256)])
+def test_ivf_models_at_any_dimension(D, de, dh):
+    """IVFBook takes any D (qinco_base.py:128-196).  The fp16-filtered coarse assignment is compiled in for the reference's dataset
+    dimensions; for every other D the kernel-instance module of the model's geometry (built on demand, or ahead of time by
+    __graft_entry__.build()) brings the exact fp32 assignment kernel for its D, zero-padded to 32-feature blocks like the MLP --
+    so an IVF model of any D <= 1024 encodes: coarse id, max(A, B) candidates on the first QINCo step, codes against the oracle."""
+    from qinco_amd import QincoConfig, QincoEngine, synth_state_dict, synth_vectors
+    cfg = QincoConfig(D=D, M=3, K=256, L=2, de=de, dh=dh, A=8, B=4, ivf_K=1000)     # (1000 centroids: not a multiple of 32 either)
+    sd = synth_state_dict(cfg, 77 + D)
+    x = synth_vectors(cfg, sd, 300, seed=5)
+    eng = QincoEngine(cfg, sd, max_batch=128)
+    oracle = make_oracle(cfg, sd)
+    want = oracle(x, step="encode").T
+    got = eng.encode(x, code_dtype=np.int32).astype(np.int64)
+    assert got.shape == (300, 4) and got[:, 0].max() < 1000
+    nbad = assert_only_near_ties(oracle, x, got, want, NEAR_TIE, f"IVF D={D}")
+    ok = (got == want).all(axis=1)
+    assert ok.sum() >= 295 and rel_err(eng.decode(got)[ok], oracle(want.T, step="decode")[ok]) < REL_TOL
+    print(f"IVF D={D}: {nbad} rows on oracle ties; kernels: {eng.describe()}")
+    eng.close()
+
+
+def test_decode_of_a_prefix_agrees_with_the_prefix_of_a_decode_in_the_default_configuration():
+    """On the two-workgroups-per-CU shapes (qinco1 / qinco2-S) a decode call picks its kernel form by its row count: small calls the
+    small-launch form (folded association T[code] + W_x xhat), calls of >= ~24 k rows the shape's un-folded instance (the reference's
+    own association in the concat layer) -- INTEGRATION.md "Behavioural differences".  The two forms are the same real-number
+    function in different fp32 associations: decode(codes[:n]) and decode(codes)[:n] must agree to rounding (<= 1e-6 relative) in the
+    DEFAULT configuration (no diagnostics flags), every form must be deterministic, and both must meet the oracle's bar."""
+    from qinco_amd import QincoEngine, synth_codes, synth_state_dict
+    from qinco_amd.config import BASELINE_CONFIGS
+    cfg = BASELINE_CONFIGS["S"]
+    sd = synth_state_dict(cfg, 1236)
+    eng = QincoEngine(cfg, sd, max_batch=1024)
+    codes = np.ascontiguousarray(synth_codes(cfg, 40000, seed=3).T)     # (n, M)
+    whole = eng.decode(codes)                       # one call of 40 000 rows: the large-launch form
+    for n in (1000, 12288):
+        part = eng.decode(codes[:n])                # the small-launch form
+        assert np.array_equal(part, eng.decode(codes[:n]))
+        assert rel_err(part, whole[:n]) < 1e-6
+    assert np.array_equal(whole, eng.decode(codes))
+    oracle = make_oracle(cfg, sd)
+    assert rel_err(whole[:512], oracle(codes[:512].T, step="decode")) < REL_TOL
+    eng.close()

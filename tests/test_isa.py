@@ -167,8 +167,29 @@ def test_support_kernels_have_no_scratch(kernels):
     for name, k in kernels.items():
         if name.startswith(("mlp_kernel", "mlp16_kernel", "mlp_small_kernel", "mlp_split_kernel", "xproj_kernel<768,384,384>")):
             continue
+        if name.startswith("dist_topk_mfma_kernel"):
+            # two workgroups per CU (256 registers) with the tile's 128 distances live to the end: what the exact arg-min ROUNDS need
+            # (T = 1, T > 32, degenerate groups) sits in scratch across the selection; nothing of it inside the table's MFMA loop
+            assert k.meta[".private_segment_fixed_size"] <= 64 and k.meta[".vgpr_count"] <= 256, (name, k.meta[".private_segment_fixed_size"])
+            mf = [i for i, x in enumerate(k.text) if isa.is_mfma(x)]
+            if not name.startswith("dist_topk_mfma_kernel<32,"):      # (D = 32, the tiny test models: one unrolled feature block, spills inside it)
+                assert not any(x.startswith("scratch_") for x in k.text[mf[0]:mf[-1] + 1]), name
+            continue
         assert k.meta[".private_segment_fixed_size"] == 0, (name, k.meta[".private_segment_fixed_size"])
         assert k.meta[".vgpr_count"] <= 512
+
+
+def test_pair_selection_runs_on_min_max_not_on_compare_and_select(kernels):
+    """select.hpp pair_top_t: the 63 + 32 comparators of the bucket-minimum sort and the 63 + 32 of the 32-key sort are
+    v_min / v_max pairs -- f32 for the threshold, f64 for the (distance, index) keys packed into a double's mantissa -- and the
+    compaction pass is five VALU instructions and one LDS write per distance.  Read back from the large-launch table kernel."""
+    k = kernels["dist_topk_mfma_kernel<128,8>"]
+    ops = [x.split()[0] for x in k.text]
+    assert sum(o == "v_min_f64" for o in ops) >= 111 and sum(o == "v_max_f64" for o in ops) >= 111
+    assert sum(o.startswith("v_cmp_le_f32") for o in ops) == 128             # one threshold test per distance
+    assert sum(o == "v_permlane32_swap_b32_e32" for o in ops) <= 64
+    mf = [i for i, x in enumerate(k.text) if isa.is_mfma(x)]
+    assert len(mf) == 128                                                    # feature-block loop body: 4 q x 8 codeword blocks x 4
 
 
 def test_lint_sees_a_drained_ring():

@@ -172,7 +172,11 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   static_assert(!SELEP || (SHR && D == DE), "SELEP: every wave reaches the epilogue's barriers, candidates live in z's registers");
   static_assert(!G8 || (SHR && P % 24 == 0 && P / 4 >= 7), "G8 is a form of the shared ring");
   static_assert(!OCC2 || (VAR & 8), "OCC2 is a form of the pinned plan");
-  static_assert(!SHR || (LDSR && P % 12 == 0 && P / 4 >= 5), "shared ring: P multiple of 12 (3 register sets, 4 issuers)");
+  // shared ring: 4 issuers, and the register rotation must restart in phase at every section (sections are multiples of P fragments):
+  // P a multiple of 12 with 3 register sets, or (round 5) a multiple of 16 with 4 -- P = 64 divides the 128-fragment sections of the
+  // short shapes (De = 128, Dh = 256), whose stream then carries no padding (P = 48 pads each to 144: 11 % dead ring groups)
+  static_assert(!SHR || (LDSR && (P % 12 == 0 || P % 16 == 0) && P / 4 >= 5), "shared ring: P multiple of 12 (3 register sets) or of 16 (4)");
+  static_assert(!G8 || P % 12 == 0, "");
   static_assert(!LDSR || SHR || (P % 3 == 0 && P >= 6 && P <= 39), "per-wave LDS rings: 4 x P KiB must fit 160 KiB");
 
   const int lane = threadIdx.x & 63;
@@ -234,7 +238,7 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
   //        same bytes: wave w DMAs only the fragments = w (mod 4) and a raw s_barrier every 4 fragments -- after the
   //        issuers' counted vmcnt -- publishes the landed group.
   const f32x4* wp = a.wstream + lane;
-  constexpr int NRING = LDSR ? 3 : P;
+  constexpr int NRING = LDSR ? ((SHR && P % 12 != 0) ? 4 : 3) : P;   // register sets of the ring (shared ring with P % 16 == 0: four)
   f32x4 ring[NRING];
   // (SELEP's keys and indices live in the tail of this array: a SECOND __shared__ object in the kernel makes hipcc order the ring's
   // LDS reads behind the LDS-DMAs in flight -- s_waitcnt vmcnt(0) in front of 142 of them in the SELEP instance of rounds 3-4)
@@ -347,9 +351,9 @@ __global__ void __launch_bounds__(256, (VAR & 256) ? 2 : 1) mlp_kernel(MlpArgs a
         __builtin_amdgcn_s_barrier();
         dma.template operator()<T + P - 4>();
       }
-      ring[(T + 2) % 3] = myring[((T + 2) % P) * 64 + lane];
+      ring[(T + 2) % NRING] = myring[((T + 2) % P) * 64 + lane];
       asm volatile("" ::: "memory");   // the ring reads keep their program order (see fragmm)
-      return ring[T % 3];
+      return ring[T % NRING];
     } else if constexpr (LDSR) {
       // fragments T, T+1 are in ring[]; fragment T+2's DMA is P-4 DMAs old; refill the slot of fragment T-1.
       wait_vm.template operator()<P - 4>();

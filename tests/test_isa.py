@@ -47,8 +47,10 @@ def production_instances():
             for v in (var & ~KHEAD, var | SELEP):
                 if (d, de, dh, p, v) in all_:
                     prod.append((d, de, dh, p, v))
-    if (128, 128, 256, 48, 332) in all_:
-        prod.append((128, 128, 256, 48, 332))
+    for p in (64, 48):
+        if (128, 128, 256, p, 332) in all_:
+            prod.append((128, 128, 256, p, 332))
+            break
     return prod
 
 
@@ -104,14 +106,15 @@ def test_production_mlp_instances(kernels, inst):
     # behind the loop -- bounded here so that growth is a decision, not an accident.
     assert not any(x.startswith("scratch_") for x in body)
     if var & OCC2:
-        assert m[".private_segment_fixed_size"] <= 64 and m[".vgpr_spill_count"] <= 16, (m[".private_segment_fixed_size"], m[".vgpr_spill_count"])
+        # (P = 64 with its fourth ring register set: 6524 keeps 18 registers = 76 B there, 4476 11 = 48 B; P = 48: 15 / 5)
+        assert m[".private_segment_fixed_size"] <= 80 and m[".vgpr_spill_count"] <= 20, (m[".private_segment_fixed_size"], m[".vgpr_spill_count"])
     else:
         assert m[".private_segment_fixed_size"] == 0 and m[".vgpr_spill_count"] == 0
     # (iii) the ring's look-ahead: inside the FFN loop every vector-memory wait is a COUNTED one -- a vmcnt(0) there drains the whole
     # LDS-DMA ring -- and nowhere between the first and the last MFMA does a vmcnt(0) sit in front of a ring read
     assert sum(isa.vmcnt_of(x) == 0 for x in body) == 0
     assert st["vmcnt0_before_ds_read"] == 0
-    if p == 48 and not (var & T16):
+    if p in (48, 64) and not (var & T16):
         # shared ring: one raw s_barrier + one refill DMA per group of 4 (8) fragments, the waits in front of them counted
         # (fragments of the up- and the down-projection, each section padded to a multiple of the ring depth: mlp_args.hpp stream_dims)
         section = -(-(want_loop // 4 // 2) // p) * p
@@ -120,7 +123,7 @@ def test_production_mlp_instances(kernels, inst):
         assert sum(x == "s_barrier" for x in body) == frags // group
         assert sum("global_load_lds_dwordx4" in x for x in body) == frags // 4
         counted = [isa.vmcnt_of(x) for x in body if isa.vmcnt_of(x) is not None]
-        assert len(counted) == frags // group and min(counted) >= 48 // 4 - 5
+        assert len(counted) == frags // group and min(counted) >= p // 4 - 5
 
 
 def small_instances():

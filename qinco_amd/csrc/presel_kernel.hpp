@@ -39,39 +39,83 @@ __global__ void __launch_bounds__(256) presel_xproj_coop_kernel(XprojArgs a) {
   for (int c = 0; c < CPW; ++c) acc[c] = zero16();
 #pragma unroll
   for (int o = 0; o < UPW; ++o) uacc[o] = zero16();
-  float rn = 0.f;
+  // Weight fragments through a register ring PF deep (round 5).  Rounds 3-4 loaded every fragment right in front of its four MFMAs:
+  // hipcc kept one or two loads in flight (`s_waitcnt vmcnt(1)` in front of nearly every MFMA group), so each of a wave's 80
+  // fragments paid most of an L2 round trip -- ~70 k cycles for 20 k cycles of matrix work, 29 us per launch of 8192 groups.  The
+  // fragments of the whole kernel are ONE sequence in consumption order -- per feature block the wave's table fragments, then its U
+  // fragments; behind the barrier its Q fragments (which depend on nothing computed here) -- and fragment i + PF is requested when
+  // fragment i is consumed: 16 x 256 cycles of matrix work ahead of every load.  Same MFMAs in the same order: same bits.
+  constexpr int FPB = (CPW + UPW) * 4;                 // fragments per feature block
+  // (D > 256: 24 feature blocks unrolled with the ring is more than hipcc's allocator copes with -- 411 spills at (768, 128, 256) --
+  // those shapes keep the load-in-front-of-use form)
+  constexpr bool PIPE = NDB <= 8;
+  constexpr int NF1 = NDB * FPB, NFQ = QPW * NEB * 4, PF = PIPE ? 16 : 1;
+  const bool has_q = a.wq != nullptr;                  // (wave-uniform; without a Q stream the ring's tail re-reads fragment 0 of W_x, never used)
+  const f32x4* const wqs = (has_q ? a.wq + (long)(wave * QPW) * NEB * 4 * 64 : a.wx) + lane;
+  auto fragment = [&]<int i>() QINCO_LAMBDA -> f32x4 {
+    if constexpr (i < NF1) {
+      constexpr int ib = i / FPB, r = i % FPB;
+      if constexpr (r < CPW * 4) return wt[(((r / 4) * NDB + ib) * 4 + r % 4) * 64];
+      else return wu[((((r - CPW * 4) / 4) * NDB + ib) * 4 + r % 4) * 64];
+    } else if constexpr (i < NF1 + NFQ) {
+      constexpr int f = i - NF1;                       // (o, ib, q) order: ((o * NEB + ib) * 4 + q)
+      return wqs[(has_q ? f : 0) * 64];
+    } else {
+      return f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  f32x4 ring[PF];
+  if constexpr (PIPE) static_for<PF>([&]<int i>() QINCO_LAMBDA { ring[i] = fragment.template operator()<i>(); });
+  auto take = [&]<int i>() QINCO_LAMBDA -> f32x4 {
+    if constexpr (!PIPE) return fragment.template operator()<i>();
+    const f32x4 w = ring[i % PF];
+    if constexpr (i + PF < NF1 + NFQ) ring[i % PF] = fragment.template operator()<i + PF>();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return w;
+  };
+  // the groups' rows of the next feature block are requested before the current block's MFMAs
+  f32x4 xr[4], hr[4];
 #pragma unroll
-  for (int ib = 0; ib < NDB; ++ib) {
+  for (int q = 0; q < 4; ++q) {
+    xr[q] = *reinterpret_cast<const f32x4*>(xp + 8 * q);
+    hr[q] = *reinterpret_cast<const f32x4*>(hp + 8 * q);
+  }
+  float rn = 0.f;
+  static_for<NDB>([&]<int ib>() QINCO_LAMBDA {
     f32x16 rb, xt;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 xq = *reinterpret_cast<const f32x4*>(xp + ib * 32 + 8 * q);
-      const f32x4 hq = *reinterpret_cast<const f32x4*>(hp + ib * 32 + 8 * q);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float t = __fsub_rn(xq[e], hq[e]);
+        const float t = __fsub_rn(xr[q][e], hr[q][e]);
         rb[4 * q + e] = t;
-        xt[4 * q + e] = hq[e];
+        xt[4 * q + e] = hr[q][e];
         rn = fmaf(t, t, rn);
       }
     }
-#pragma unroll
-    for (int c = 0; c < CPW; ++c)
+    if constexpr (ib + 1 < NDB) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 w = wt[((c * NDB + ib) * 4 + q) * 64];
+        xr[q] = *reinterpret_cast<const f32x4*>(xp + (ib + 1) * 32 + 8 * q);
+        hr[q] = *reinterpret_cast<const f32x4*>(hp + (ib + 1) * 32 + 8 * q);
+      }
+    }
+    static_for<CPW>([&]<int c>() QINCO_LAMBDA {
+      static_for<4>([&]<int q>() QINCO_LAMBDA {
+        const f32x4 w = take.template operator()<ib * FPB + c * 4 + q>();
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[c] = QINCO_MFMA(w[e], rb[4 * q + e], acc[c]);
-      }
-#pragma unroll
-    for (int o = 0; o < UPW; ++o)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 w = wu[((o * NDB + ib) * 4 + q) * 64];
+      });
+    });
+    static_for<UPW>([&]<int o>() QINCO_LAMBDA {
+      static_for<4>([&]<int q>() QINCO_LAMBDA {
+        const f32x4 w = take.template operator()<ib * FPB + CPW * 4 + o * 4 + q>();
 #pragma unroll
         for (int e = 0; e < 4; ++e) uacc[o] = QINCO_MFMA(w[e], xt[4 * q + e], uacc[o]);
-      }
-  }
+      });
+    });
+  });
   rn += __shfl_xor(rn, 32);
   // distances (|r|^2 + |c|^2) - 2 r.c (the reference's association, utils.py:336-346) into row j of the shared table
 #pragma unroll
@@ -101,20 +145,16 @@ __global__ void __launch_bounds__(256) presel_xproj_coop_kernel(XprojArgs a) {
   __syncthreads();
   if (a.wq) {   // FOLD2 (wave-uniform): this wave's output blocks of Q = W_up[0] . U
     float* qp = a.qproj + g * DH + half * 4;
-    const f32x4* wq = a.wq + (long)(wave * QPW) * NEB * 4 * 64 + lane;
-#pragma unroll
-    for (int o = 0; o < QPW; ++o) {
+    static_for<QPW>([&]<int o>() QINCO_LAMBDA {
       f32x16 qacc = zero16();
-#pragma unroll
-      for (int ib = 0; ib < NEB; ++ib) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+      static_for<NEB>([&]<int ib>() QINCO_LAMBDA {
+        static_for<4>([&]<int q>() QINCO_LAMBDA {
           const f32x4 ub = ubuf[(ib * 4 + q) * 64 + lane];
-          const f32x4 w = wq[((o * NEB + ib) * 4 + q) * 64];
+          const f32x4 w = take.template operator()<NF1 + (o * NEB + ib) * 4 + q>();
 #pragma unroll
           for (int e = 0; e < 4; ++e) qacc = QINCO_MFMA(w[e], ub[e], qacc);
-        }
-      }
+        });
+      });
       if (valid) {
         const int ob = wave * QPW + o;
 #pragma unroll
@@ -123,7 +163,7 @@ __global__ void __launch_bounds__(256) presel_xproj_coop_kernel(XprojArgs a) {
           *reinterpret_cast<f32x4*>(qp + ob * 32 + 8 * q) = t;
         }
       }
-    }
+    });
   }
   coop_select_rows<K, LDK, SGP>(table, surv_all + wave * SGP * SEL_SURV, lane, wave, g0, a.G, a.T, a.ids_out);
 }

@@ -145,16 +145,35 @@ dist_topk_mfma_coop_kernel(const float* __restrict__ x, const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
   float rn = 0.f;
+  // fragments in consumption order (feature block, codeword block of this wave, q) through a register ring 16 deep, the groups' rows
+  // of the next feature block requested before the current block's MFMAs (round 5: loaded in front of their MFMAs the fragments each
+  // paid an L2 round trip -- see presel_kernel.hpp)
+  constexpr int NF = NDB * CPW * 4, PF = NF < 16 ? NF : 16;
+  auto fragment = [&](int i) -> f32x4 {
+    const int ib = i / (CPW * 4), r = i % (CPW * 4);
+    return wp[(((r / 4) * NDB + ib) * 4 + r % 4) * 64];
+  };
+  f32x4 ring[PF];
 #pragma unroll
+  for (int i = 0; i < PF; ++i) ring[i] = fragment(i);
+  f32x4 xr[4], hr[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    xr[q] = *reinterpret_cast<const f32x4*>(xp + 8 * q);
+    if (hp) hr[q] = *reinterpret_cast<const f32x4*>(hp + 8 * q);
+  }
+  // (wide data: the feature-block loop unrolled by two only -- a ring slot is (8 ib + r) % 16 --; unrolled 24 times the D = 768
+  // instance needs 512 registers and spills inside the loop)
+  constexpr int IBU = (NDB > 8 && NDB % 2 == 0 && CPW * 4 * 2 == PF) ? 2 : NDB;
+#pragma unroll IBU
   for (int ib = 0; ib < NDB; ++ib) {
     f32x16 rb;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 t = *reinterpret_cast<const f32x4*>(xp + ib * 32 + 8 * q);
+      f32x4 t = xr[q];
       if (hp) {
-        const f32x4 hq = *reinterpret_cast<const f32x4*>(hp + ib * 32 + 8 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = __fsub_rn(t[e], hq[e]);
+        for (int e = 0; e < 4; ++e) t[e] = __fsub_rn(t[e], hr[q][e]);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -162,11 +181,22 @@ dist_topk_mfma_coop_kernel(const float* __restrict__ x, const float* __restrict_
         rn = fmaf(t[e], t[e], rn);
       }
     }
+    if (ib + 1 < NDB) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xr[q] = *reinterpret_cast<const f32x4*>(xp + (ib + 1) * 32 + 8 * q);
+        if (hp) hr[q] = *reinterpret_cast<const f32x4*>(hp + (ib + 1) * 32 + 8 * q);
+      }
+    }
 #pragma unroll
     for (int c = 0; c < CPW; ++c)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 w = wp[((c * NDB + ib) * 4 + q) * 64];
+        const int i = (ib * CPW + c) * 4 + q;
+        const f32x4 w = ring[i % PF];
+        if (i + PF < NF) ring[i % PF] = fragment(i + PF);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], rb[4 * q + e], acc[c], 0, 0, 0);
       }

@@ -68,7 +68,8 @@ def compact_code_dtype(K: int, cols: int, M: int):
 
 def encode_shard(model: Callable, db_vecs, start: int, end: int, batch: int = 65536,
                  to_device: Optional[Callable] = None, sink: Optional[Callable] = None, pipeline: bool = True,
-                 code_dtype=np.int64, keep: bool = True, K: Optional[int] = None, M: Optional[int] = None) -> Optional[np.ndarray]:
+                 code_dtype=np.int64, keep: bool = True, K: Optional[int] = None, M: Optional[int] = None,
+                 stats: Optional[dict] = None) -> Optional[np.ndarray]:
     """Encode rows [start, end) in batches: codes (end-start, M) in file order (search_tasks.py:107-116).
     `model(x, step="encode")` returns (M, n) like the reference's model object.  sink(codes_batch): called with every
     batch's codes as they arrive (the part-file writer compresses them while the GPU encodes the next batch).
@@ -82,8 +83,10 @@ def encode_shard(model: Callable, db_vecs, start: int, end: int, batch: int = 65
     narrowing / sink of the previous batch's codes -- runs on two helper threads while the model call (which releases
     the GIL inside libqinco_hip) keeps the GPU busy.  The reference does all of it serially (search_tasks.py:107-116), which
     is free next to its CPU encode and 15 % of the wall clock next to a qinco2-S encode on the GPU.  Same results, same order."""
+    import time as _time
     bounds = [(i0, min(end, i0 + batch)) for i0 in range(start, end, batch)]
     state = {"out": None}
+    tm = {"model_s": 0.0, "wait_load_s": 0.0, "wait_finish_s": 0.0, "batches": len(bounds)}   # where the driving thread's time went (stats)
     if not bounds:
         return np.zeros((0, 0), np.int64) if keep else None
 
@@ -140,14 +143,25 @@ def encode_shard(model: Callable, db_vecs, start: int, end: int, batch: int = 65
             nxt = loader.submit(load, 0) if prefetch else None
             done = None
             for k in range(len(bounds)):
+                t0 = _time.perf_counter()
                 xb = nxt.result() if prefetch else load(k)
                 if prefetch and k + 1 < len(bounds):
                     nxt = loader.submit(load, k + 1)
+                t1 = _time.perf_counter()
                 codes = model(xb, step="encode")
+                t2 = _time.perf_counter()
                 if done is not None:
                     done.result()                       # (surfaces exceptions of the previous batch's post-processing)
                 done = finisher.submit(finish, k, codes, event_of(codes))
+                t3 = _time.perf_counter()
+                tm["wait_load_s"] += t1 - t0
+                tm["model_s"] += t2 - t1
+                tm["wait_finish_s"] += t3 - t2
+            t3 = _time.perf_counter()
             done.result()
+            tm["wait_finish_s"] += _time.perf_counter() - t3
+    if stats is not None:
+        stats.update(tm)
     if not keep:
         return None
     out = state["out"]
@@ -212,11 +226,13 @@ class PartFileWriter:
     each deflated independently on a thread pool (zlib releases the GIL) and closed with a sync flush, so that their
     concatenation is ONE valid raw-deflate stream; chunks are compressed while later batches are still being encoded.
     rows / M must be known up front (the .npy header comes first in the stream); zip64 records are always written (numpy
-    does the same: force_zip64)."""
+    does the same: force_zip64).  zlib level 4 (numpy: 6): on int64 code rows 11 ms instead of 70 ms per MiB for files 1.6 % larger
+    (0.2113 against 0.2080 of the raw size) -- what remains to deflate behind the last batch is what a job waits for at the end, and
+    the last rows are cut into one piece per thread (round 5: the tail of a 10^6-vector qinco2-S job 38-71 ms -> see HISTORY)."""
 
     CHUNK = 1 << 20
 
-    def __init__(self, path: str, rows: int, M: int, threads: int = 8, level: int = 6):
+    def __init__(self, path: str, rows: int, M: int, threads: int = 8, level: int = 4):
         import concurrent.futures as cf
         import io
         import struct
@@ -276,14 +292,25 @@ class PartFileWriter:
         self._seen += len(codes)
         self._buf += codes.tobytes()
         self._finished = False
+        if self._seen == self.rows and len(self._buf) > 0:
+            # the last rows: everything still buffered is cut into one piece per thread (>= 64 KiB) and closed now, so that close()
+            # finds the stream finished instead of waiting for whole 1 MiB chunks
+            piece = max(64 << 10, -(-len(self._buf) // self._pool._max_workers))
+            piece = min(piece, self.CHUNK)
+            chunk, self.CHUNK = self.CHUNK, piece
+            try:
+                self._submit(True)
+            finally:
+                self.CHUNK = chunk
+            return
         self._submit(False)
 
     def close(self):
         import struct
         assert self._seen == self.rows, f"{self._seen} of {self.rows} rows written"
-        self._finished = False
-        self._submit(True)
-        if not self._finished:       # nothing was left to flush (the data ended on a chunk boundary): terminate the stream
+        if not getattr(self, "_finished", False):
+            self._submit(True)
+        if not getattr(self, "_finished", False):       # nothing was left to flush (an empty file, or the data ended on a chunk boundary): terminate the stream
             self._futs.append(self._pool.submit(self._deflate, b"", True))
         self._drain(True)
         f, name = self._f, self._name
@@ -327,7 +354,7 @@ def _barrier(dist, device=None):
 
 def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D: int, batch: int = 65536,
                     dist=None, gather: bool = False, to_device: Optional[Callable] = None, device=None,
-                    writer_threads: int = 8, resume: bool = False, code_dtype=np.int64, keep: bool = True):
+                    writer_threads: int = 8, resume: bool = False, code_dtype=np.int64, keep: bool = True, stats: Optional[dict] = None):
     """Reference-compatible database encode.  Returns this rank's codes; with gather=True rank 0 returns the
     whole (N, M) code matrix collected with one collective (other ranks: their own shard).  `device`: where the
     collective's buffers live (default: this rank's current GPU under backend "nccl", the host under "gloo").
@@ -370,7 +397,7 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
             codes = None
     else:
         codes = encode_shard(model, db_vecs, start, end, batch, to_device, sink if (writer_threads > 0 and end > start) else None,
-                             code_dtype="compact", keep=keep, K=K, M=M)
+                             code_dtype="compact", keep=keep, K=K, M=M, stats=stats)
     writer = state["writer"]
     if codes is not None and codes.size == 0:
         codes = np.zeros((0, M), compact_code_dtype(K, M, M))
@@ -382,7 +409,11 @@ def encode_database(model: Callable, db_vecs, output: str, *, K: int, M: int, D:
             os.makedirs(d, exist_ok=True)
         np.savez_compressed(output, n_parts=world, K=K, M=M, D=D)
     if writer is not None:
+        import time as _time
+        t0 = _time.perf_counter()
         writer.close()
+        if stats is not None:
+            stats["writer_close_s"] = _time.perf_counter() - t0
     elif done is None and (keep or end == start):
         # (no writer: writer_threads = 0, or an EMPTY shard -- N < world -- which never reaches the sink: the header says
         # n_parts = world, so every rank owes the readers a part file, also with keep=False)

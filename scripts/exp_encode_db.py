@@ -39,9 +39,10 @@ with tempfile.TemporaryDirectory(prefix="qinco_exp_") as tmp:
                            ("memmap batch 262144, compact codes", db, dict(batch=262144, code_dtype="compact"))):
         out = os.path.join(tmp, f"enc_{abs(hash(label))}", "db.npz")
         t0 = time.perf_counter()
-        encode_database(model, src, out, K=cfg.K, M=cfg.M, D=cfg.D, **kw)
+        st = {}
+        encode_database(model, src, out, K=cfg.K, M=cfg.M, D=cfg.D, stats=st, **kw)
         dt = time.perf_counter() - t0
-        print(f"{wl} {label}: {n_db / dt:.0f} vec/s ({dt:.2f} s)", flush=True)
+        print(f"{wl} {label}: {n_db / dt:.0f} vec/s ({dt:.2f} s) " + " ".join(f"{k}={v:.3f}" if isinstance(v, float) else f"{k}={v}" for k, v in st.items()), flush=True)
     xd = torch.from_numpy(ram[:262144]).cuda()
     model.engine.encode(xd[:16384], code_dtype=np.uint8)
     torch.cuda.synchronize()

@@ -85,7 +85,7 @@ def pmc_traffic_per_row():
     """L2<->fabric bytes per MLP row from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
     WRITE_SIZE).  Counters cannot be read from inside this process, so the figure of the separate PMC run of this
     same command is scaled to this run's rows per launch."""
-    for name in ("r04_c2_traffic.json", "r03_c2_traffic.json", "r02_c2_traffic.json", "r01_c2_traffic.json"):
+    for name in ("r05f_c2_traffic.json", "r04_c2_traffic.json", "r03_c2_traffic.json", "r02_c2_traffic.json", "r01_c2_traffic.json"):
         try:
             with open(ROOT / "profiles" / name) as f:
                 return float(json.load(f)["bytes_per_row"]), name

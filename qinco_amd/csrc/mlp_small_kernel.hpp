@@ -43,11 +43,18 @@ struct SmallPlan {
   int LAG;          // a ring slot is refilled LAG reads after it was read
   unsigned lds_bytes;
 };
+// Decode's head GEMM U = W_x xhat reads the workgroup's xhat tile from LDS: NDB 16-feature blocks x NT row tiles of 1 KiB.  At
+// D = 768 that is 48 KiB per row tile, more than fits next to the rings for NT > 1: the tile is then published in chunks of
+// kSmallHeadChunk blocks and the GEMM's accumulation chains run on across the chunks (same products, same order: same bits).
+constexpr int kSmallHeadChunk = 16;
+constexpr int small_head_chunk(int NDB) { return (NDB > 24 && NDB % kSmallHeadChunk == 0) ? kSmallHeadChunk : NDB; }
 constexpr SmallPlan small_plan(int D, int DE, int DH, int NT, bool fold2, bool dec) {
   const SmallDims S = small_dims(D, DE, DH, fold2);
   SmallPlan p{};
   int actb = S.NEB > S.NHB ? S.NEB : S.NHB;
-  if (dec && S.NDB > actb) actb = S.NDB;
+  if (dec && small_head_chunk(S.NDB) > actb) actb = small_head_chunk(S.NDB);
+  // (registers: a decode wave carries xhat, c and the next step's c for its NDW blocks of every row tile -- 18 x 4 NT at D = 768)
+  if (dec && S.NDW * NT > 12) return p;   // (NT = 3 at D = 768 compiles to 74-103 spilled registers with scratch traffic inside the GEMMs)
   int nobmax = S.NEW > S.NHW ? S.NEW : S.NHW;
   if (S.PROJ && S.NDW > nobmax) nobmax = S.NDW;
   p.ACTB = actb;
@@ -104,7 +111,7 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
   constexpr bool DB = PL.DB;
   constexpr int SLOT4 = PL.ACTB * NT * 64;   // f32x4 per activation buffer
   static_assert(PROJ || NDW == NEW, "identity projections: De == D");
-  constexpr bool LATE = DEC && (NEW + NHW) * NT > 16;   // table gathers after their GEMM (register budget: 256 per wave)
+  constexpr bool LATE = DEC && ((NEW + NHW) * NT > 16 || NDW * NT > 8);   // table gathers after their GEMM (register budget: 256 per wave)
 
   extern __shared__ __attribute__((aligned(16))) f32x4 lds_small[];
   const int lane = threadIdx.x & 63;
@@ -186,7 +193,7 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
   // The GEMM can HOST G independent loads (table rows of the next decode step), GPF of them behind each of its first ring reads:
   // vmcnt counts in order, so a load issued between two ring DMAs must be counted by every ring wait that looks across it
   // (hosted_extra) -- issued in one batch in front of a GEMM the same loads would stop its first ring read for their whole latency.
-  auto gemm_hosting = [&]<int NIB, int NOW, int G, int GPF>(f32x4 (&acc)[NOW][NT], const f32x4* src, auto&& gf) QINCO_LAMBDA {
+  auto gemm_hosting = [&]<int NIB, int NOW, int G, int GPF, bool ZERO = true>(f32x4 (&acc)[NOW][NT], const f32x4* src, auto&& gf) QINCO_LAMBDA {
     constexpr int WIN = PW - LAG;
     static_assert(G == 0 || NOW + (G + GPF - 1) / GPF - 1 + WIN <= NIB * NOW - 1, "hosted loads must age out inside the GEMM");
     f32x4 wf[NOW];
@@ -194,10 +201,12 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
     static_for<NOW>([&]<int j>() QINCO_LAMBDA { wf[j] = ring_read.template operator()<0>(); });
 #pragma unroll
     for (int t = 0; t < NT; ++t) bn[t] = src[t * 64 + lane];
+    if constexpr (ZERO) {   // (a chunk of a longer contraction continues the chains it is handed)
 #pragma unroll
-    for (int j = 0; j < NOW; ++j)
+      for (int j = 0; j < NOW; ++j)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[j][t] = zero4;
+        for (int t = 0; t < NT; ++t) acc[j][t] = zero4;
+    }
     auto body = [&]<bool LAST, int ib>() QINCO_LAMBDA {
       f32x4 bc[NT];
 #pragma unroll
@@ -235,6 +244,9 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
   auto gemm = [&]<int NIB, int NOW>(f32x4 (&acc)[NOW][NT], const f32x4* src) QINCO_LAMBDA {
     gemm_hosting.template operator()<NIB, NOW, 0, 1>(acc, src, no_gather);
   };
+  auto gemm_more = [&]<int NIB, int NOW>(f32x4 (&acc)[NOW][NT], const f32x4* src) QINCO_LAMBDA {
+    gemm_hosting.template operator()<NIB, NOW, 0, 1, false>(acc, src, no_gather);
+  };
 
   // activation buffers: the GEMM after a publish reads what the publish wrote
   int cur = 0;
@@ -246,6 +258,20 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
       if (NW * j + wave_u < NB) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) dst[((NW * j + wave_u) * NT + t) * 64 + lane] = v[j][t];
+      }
+    });
+    barrier();
+  };
+  // blocks [B0, B0 + NB) of a tile whose blocks NW j + wave this wave holds, to positions 0 .. NB - 1 of the buffer
+  auto publish_chunk = [&]<int NOW, int B0, int NB>(const f32x4 (&v)[NOW][NT]) QINCO_LAMBDA {
+    if constexpr (DB) cur ^= 1;
+    else barrier();
+    f32x4* dst = act + cur * SLOT4;
+    static_for<NOW>([&]<int j>() QINCO_LAMBDA {
+      const int b = NW * j + wave_u;
+      if (b >= B0 && b < B0 + NB) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dst[((b - B0) * NT + t) * 64 + lane] = v[j][t];
       }
     });
     barrier();
@@ -305,7 +331,8 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
   constexpr int F_DOWN0 = NHB * NEW;                              // fragments of the down-projection per wave
   constexpr int HOST_ROOM = F_DOWN0 - 1 - (PW - LAG) - NEW + 1;   // ring reads of that GEMM that can host loads
   constexpr int GPF = HOST_ROOM > 0 ? (G_HOST + HOST_ROOM - 1) / HOST_ROOM : 99;
-  constexpr bool HOST = DEC && FOLD2 && !LATE && GPF <= 4 && PW - LAG - 1 + GPF * (PW - LAG) <= 63;
+  // (wide data with several row tiles: a second set of c rows for the next step does not fit the 256 registers of a wave)
+  constexpr bool HOST = DEC && FOLD2 && !LATE && GPF <= 4 && PW - LAG - 1 + GPF * (PW - LAG) <= 63 && NDW * NT <= 8;
   f32x4 cgn[HOST ? NDW : 1][NT];   // HOST: c rows of the next step (cg is still needed by this step's epilogue)
 
   // One step's MLP up to the last down-projection: z.  Decode: st / cid = this step, stn / cidn = the next one (HOST).
@@ -316,9 +343,22 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
     int l0 = 0;
     if constexpr (DEC) {
       // ---- head in the kernel: U = W_x xhat (chain from zero, xproj_kernel's order), z = T[code] + U ---------------------
-      publish.template operator()<NDW, NDB>(xh);
-      stamp();   // step + 0: xhat published
-      gemm.template operator()<NDB, NEW>(acc_e, src_buf());
+      constexpr int HC = small_head_chunk(NDB);
+      if constexpr (HC == NDB) {
+        publish.template operator()<NDW, NDB>(xh);
+        stamp();   // step + 0: xhat published
+        gemm.template operator()<NDB, NEW>(acc_e, src_buf());
+      } else {   // D = 768: the xhat tile in chunks of HC blocks, the chains run on across them
+        static_for<NDB / HC>([&]<int c>() QINCO_LAMBDA {
+          publish_chunk.template operator()<NDW, c * HC, HC>(xh);
+          if constexpr (c == 0) {
+            stamp();
+            gemm.template operator()<HC, NEW>(acc_e, src_buf());
+          } else {
+            gemm_more.template operator()<HC, NEW>(acc_e, src_buf());
+          }
+        });
+      }
       stamp();   // step + 1: U = W_x xhat
       if constexpr (FOLD2) publish.template operator()<NEW, NEB>(acc_e);   // U is the input of Q = W_up[0] U
       if constexpr (LATE) gather_t(st, cid);
@@ -410,11 +450,13 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
   };
 
   // ---- out_proj + (o + c) + xhat for this wave's blocks of D: o[j][t] --------------------------------------------------------
-  auto out_blocks = [&](f32x4 (&o)[NDW][NT], const f32x4 (&xprev)[NDW][NT]) QINCO_LAMBDA {
+  auto out_blocks = [&](f32x4 (&o)[NDW][NT], const f32x4 (&xprev)[NDW][NT], auto&& after_gemm) QINCO_LAMBDA {
     if constexpr (PROJ) {
       publish.template operator()<NEW, NEB>(z);
       gemm.template operator()<NEB, NDW>(o, src_buf());
+      after_gemm();
     } else {
+      after_gemm();
       static_for<NDW>([&]<int j>() QINCO_LAMBDA {
 #pragma unroll
         for (int t = 0; t < NT; ++t) o[j][t] = z[j][t];
@@ -460,9 +502,10 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
       const SmallStep stn = a.steps[m < m_last ? m + 1 : m_last];
       codes_of(m + 2, cid_n2);
       run_step(st, stn, cid_n1);
-      if constexpr (LATE) gather_c(st, cid, cg);
       f32x4 o[NDW][NT];
-      out_blocks(o, xh);
+      out_blocks(o, xh, [&]() QINCO_LAMBDA {
+        if constexpr (LATE) gather_c(st, cid, cg);   // (behind the out_proj GEMM: the c rows do not sit in registers across it)
+      });
       static_for<NDW>([&]<int j>() QINCO_LAMBDA {
 #pragma unroll
         for (int t = 0; t < NT; ++t) xh[j][t] = o[j][t];
@@ -526,7 +569,7 @@ __global__ void __launch_bounds__(64 * kSmallWaves, 1) mlp_small_kernel(SmallArg
     });
     run_step(st, st, cid);
     f32x4 o[NDW][NT];
-    out_blocks(o, xprev);
+    out_blocks(o, xprev, []() QINCO_LAMBDA {});
     // the candidate tile in natural layout (rows D + 4 floats apart), over the activation buffers
     constexpr int CS = D + 4;
     float* ct = reinterpret_cast<float*>(act);

@@ -658,6 +658,14 @@ def main():
                     torch.cuda.set_device(dev_index)
                     probe = torch.ones(1, device=dev)
                     dist.all_reduce(probe, group=data_group)
+                    # ... and the gather's own point-to-point pattern once with one byte per rank: whatever the backend builds lazily
+                    # for a (rank, 0) pair is built here, not inside the timed region
+                    if rank == 0:
+                        box = torch.zeros(world, dtype=torch.uint8, device=dev)
+                        for q in [dist.irecv(box[r:r + 1], src=r, group=data_group) for r in range(1, world)]:
+                            q.wait()
+                    else:
+                        dist.send(torch.full((1,), rank, dtype=torch.uint8, device=dev), dst=0, group=data_group)
                     torch.cuda.synchronize(dev)
                 call_with_timeout(probe_rccl, args.rccl_timeout)
             except BaseException as e:                        # noqa: BLE001 -- any failure or a hang: part files instead

@@ -4,6 +4,7 @@
 # Outputs -> gpurun_out/r05f_*  (copy what is to be judged into profiles/).
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp; export ROUND=r05f
 timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/r05f_pytest_gpu.txt 2>&1; tail -n 3 $O/r05f_pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 1
 timeout 1500 python bench.py > $O/r05f_bench_c2_n1.json 2> $O/r05f_bench.err; head -c 300 $O/r05f_bench_c2_n1.json; echo
 cd /tmp
 prof() {  # name, rocprof args..., then the command after --

@@ -13,8 +13,8 @@ __global__ void __launch_bounds__(64) selftest_sort_kernel(const unsigned* __res
   out[(long)blockIdx.x * 64 + lane] = wave_sort64(in[(long)blockIdx.x * 64 + lane]);
 }
 // pair_top_t (select.hpp) on tiles of 32 rows x 256 distances given in memory: lane (j, half) loads row j in the MFMA C layout
-// (codeword 32 cb + 8 gq + 4 half + e -> register 16 cb + 4 gq + e).  coop != 0: the cooperative kernels' form -- 8 rows per wave, lanes
-// j >= 8 repeat them, 16 lists.
+// (codeword 32 cb + 8 gq + 4 half + e -> register 16 cb + 4 gq + e).  coop != 0: 8 rows per wave, the other lanes repeat them and
+// do not store (a wave with most of its pairs idle).
 __global__ void __launch_bounds__(64) selftest_pair_kernel(const float* __restrict__ d, int T, int* __restrict__ ids, int coop,
                                                            int* __restrict__ rounds) {
   __shared__ __attribute__((aligned(16))) unsigned lists[pair_lds_words<64>()];
@@ -35,8 +35,7 @@ __global__ void __launch_bounds__(64) selftest_pair_kernel(const float* __restri
     ids[blockIdx.x * 128 + 64 + lane] = (int)pair_partner((double)lane * 0.5 + 7.0, half);
     return;
   }
-  if (coop) pair_top_t<8, 16>(acc, lane, T, lists, ids + row * T, j < 8, rounds + row);
-  else pair_top_t<8, 64>(acc, lane, T, lists, ids + row * T, true, rounds + row);
+  pair_top_t<8>(acc, lane, T, lists, ids + row * T, coop ? j < 8 : true, rounds + row);
 }
 
 __global__ void __launch_bounds__(64) selftest_select_kernel(const float* __restrict__ d, int C, int T, int* __restrict__ ids,

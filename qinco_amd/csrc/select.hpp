@@ -244,10 +244,12 @@ constexpr int PAIR_LIST = 24;                   // survivors a lane can hold (on
 constexpr int PAIR_GROUP_MAX = 32;              // survivors of a group the sort takes
 constexpr int PAIR_T_MAX = 16;                  // largest T of the fast path: for T = 17 .. 32 a threshold from 32 bucket minima leaves ~100 survivors
 constexpr unsigned PAIR_SENTINEL = 0x7fffffffu; // distance bits of an empty list entry (a positive NaN: never a survivor's)
-// unsigned of LDS per wave: [entry][list][distance bits, codeword] with NL lists -- one per lane (64), or 16 when only lanes
-// j < 8 of each half own a group (the cooperative small-launch kernels: the other lanes repeat them and write the same values)
-template <int NL>
-constexpr int pair_lds_words() { return (PAIR_LIST + 1) * NL * 2; }
+// unsigned of LDS per wave: [entry][lane][distance bits, codeword]
+template <int NL = 64>
+constexpr int pair_lds_words() {
+  static_assert(NL == 64, "one list per lane");
+  return (PAIR_LIST + 1) * NL * 2;
+}
 
 constexpr int kSort16[63][2] = {
     {0, 1},   {2, 3},   {4, 5},   {6, 7},   {8, 9},   {10, 11}, {12, 13}, {14, 15}, {0, 2},   {1, 3},   {4, 6},   {5, 7},   {8, 10},
@@ -349,16 +351,15 @@ QINCO_DEV void pair_rounds(const f32x16 (&acc)[NKB], int half, int T, bool mine,
   }
 }
 
-// acc: the lane's 16 NKB distances; lists: pair_lds_words<NL>() unsigned of LDS private to this wave; out: ids_out + group * T
+// acc: the lane's 16 NKB distances; lists: pair_lds_words<64>() unsigned of LDS private to this wave; out: ids_out + group * T
 // (written when store).  All 64 lanes must be active; lanes whose group is a copy (past the end of the launch) pass store = false.
-template <int NKB, int NL = 64>
+template <int NKB>
 QINCO_DEV void pair_top_t(const f32x16 (&acc)[NKB], int lane, int T, unsigned* lists, int* __restrict__ out, bool store,
                           int* __restrict__ went_to_rounds = nullptr) {
-  static_assert(NKB == 8, "16 buckets of 8 registers per lane: K = 256");
-  static_assert(NL == 64 || NL == 16, "");
-  constexpr int ES = NL * 2;                                                       // words per entry row
+  static_assert(NKB == 8, "32 quads per lane: K = 256");
+  constexpr int NL = 64, ES = NL * 2;                                              // lists per wave, words per entry row
   const int half = lane >> 5;
-  const int li = NL == 64 ? lane : ((lane & 7) | (half << 3));                     // this lane's list
+  const int li = lane;                                                             // this lane's list
   bool redo = true;   // this lane's group still has to go through the rounds
   int dbg_S = 0;
   if (T >= 2 && T <= PAIR_T_MAX) {   // (wave-uniform)

@@ -436,6 +436,13 @@ def leg_workload(torch, dev, name, steps, batch, oracle_sample=0, decode_sizes=(
         dt_o = time.perf_counter() - t1
         same = int((got == want).all(axis=1).sum())
         out["greedy_rows_equal_to_oracle"] = f"{same}/{oracle_sample}"
+        if same < oracle_sample:      # every differing row must sit on a rounding-level tie of the oracle's own selection (tests/conftest.py)
+            try:
+                sys.path.insert(0, str(ROOT / "tests"))
+                from conftest import assert_only_near_ties
+                out["differing_rows_on_oracle_ties_below_2e-5"] = int(assert_only_near_ties(oracle, x, got, want, 2e-5, "c1 leg"))
+            except AssertionError as e:
+                out["differing_rows_on_oracle_ties_below_2e-5"] = f"NO: {e}"[:300]
         out["cpu_baseline"] = {"value": oracle_sample / dt_o, "unit": "vectors/s", "cores": threads, "kind": "port",
                                "gflops": oracle_sample / dt_o * cfg.encode_flops_per_vector() / 1e9,
                                "sample": f"the same {oracle_sample} vectors in oracle calls of <= 1024 ({dt_o:.1f} s, {threads} ATen threads; "

@@ -259,6 +259,16 @@ QINCO_API int qinco_knn_destroy(qinco_knn knn);
  * device; enqueued on `stream`, not synchronised. */
 QINCO_API int qinco_knn_search(qinco_knn knn, const float* db, int64_t n, const float* queries, int64_t nq, int32_t k,
                                int64_t* ids_out, float* dist_out, void* stream);
+/* Large databases take a FILTERED form that never writes the (queries x n) table (csrc/knn_kernel.hpp: thresholds from a strided
+ * sample of the database, the whole table on the matrix pipe with only the pairs under their query's threshold kept, those sorted);
+ * same ids and distances bit for bit; a chunk of queries whose candidate lists overflow is redone unfiltered on the device.
+ * Options: QINCO_KNN_OPT_FILTER 0 = never / 1 = where it pays (default); QINCO_KNN_OPT_FILTER_MIN_N = smallest n that takes it
+ * (default 65536).  qinco_knn_last_stats (synchronises the device): out3 = {chunks of queries of the last search, chunks that took
+ * the filtered form, chunks that were redone unfiltered}. */
+#define QINCO_KNN_OPT_FILTER 0
+#define QINCO_KNN_OPT_FILTER_MIN_N 1
+QINCO_API int qinco_knn_set_option(qinco_knn knn, int32_t option, int64_t value);
+QINCO_API int qinco_knn_last_stats(qinco_knn knn, int64_t* out3);
 /* the same on host buffers; synchronous */
 QINCO_API int qinco_knn_search_host(qinco_knn knn, const float* db, int64_t n, const float* queries, int64_t nq, int32_t k,
                                     int64_t* ids_out, float* dist_out);

@@ -15,6 +15,18 @@
 //                        until the k-th key's bucket and everything below it fit an LDS buffer, one compaction pass
 //                        collects them, a bitonic sort orders them.  Ties resolve to the lower index (stable argsort).
 //                        HBM-bound: the row is read 2 (rarely 3+) times: 8-12 B per pair.
+// Large databases (round 5) take the FILTERED form instead, which never writes the (queries x db) table: 4 B written and
+// 8-12 B read per pair made the search HBM-bound at half the matrix pipe's rate (40 GB of table per 10^4 queries x 10^6 rows).
+//   (1) the two kernels above on a strided 1/s SAMPLE of the database (rows 0, s, 2s, ...) give tau[q] = the k-th smallest
+//       key of the sample: an upper bound of the k-th smallest key of the whole database (the sample is a subset);
+//   (2) knn_table_kernel<D, FILT = true> computes the whole table on the matrix pipe -- the same instruction sequence per
+//       pair, hence the same bits -- and appends only the pairs with key <= tau[q] to the query's candidate list
+//       (about k s of them; one L2 atomic per survivor, 0.2 % of the pairs);
+//   (3) knn_cand_select_kernel sorts each query's candidates as 64-bit (distance, index) keys in LDS: the first k.
+// The candidate set contains the k smallest keys whatever the data (every key <= the k-th smallest is <= tau), so the
+// result is the unfiltered form's bit for bit.  A list that overflows its kKnnCap slots (adversarial data: thousands of
+// rows at exactly tau) or holds fewer than k keys (NaN distances) raises the chunk's flag, and the unfiltered kernels --
+// enqueued behind it, predicated on that flag -- redo the chunk: no host round trip, the call stays asynchronous.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -52,19 +64,57 @@ knn_pack_rows_kernel(const float* __restrict__ rows, long n, int D, f32x4* __res
   }
 }
 
-template <int D>
-__global__ void __launch_bounds__(256)
+constexpr int kKnnCap = 8192;      // LDS candidate buffer (64 KiB of 64-bit keys) = slots of a query's candidate list
+constexpr int kKnnThreads = 1024;
+constexpr int kKnnMaxK = 2048;
+
+__device__ __forceinline__ unsigned knn_key_hi(float d) {
+  const unsigned u = __builtin_bit_cast(unsigned, d);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> unsigned (NaNs sort last)
+}
+
+// The filtered form's arguments (FILT = true); `pred` also predicates the unfiltered form when it runs as the fall-back.
+struct KnnFilt {
+  const unsigned* tau;        // per query row of the chunk: high word of the k-th smallest key of the sample
+  unsigned* cnt;              // per query row: candidates appended (may exceed kKnnCap: the list overflowed)
+  unsigned long long* cand;   // (chunk, kKnnCap) keys
+  int nq_valid;               // query rows of the chunk (rows beyond are padding of the last block)
+  const int* pred;            // nullptr: always run; else run only if *pred != 0
+};
+
+// database row of tile column c = c * row_stride (row_stride = 1: the database itself; s: its strided sample, N = sample rows)
+//
+// FILT: nothing of the table is stored.  The thresholds of the chunk's query rows sit in LDS; behind a block's MFMAs every
+// (query, 32 database rows) slice of the tile is compared with its threshold and the wave votes: `__ballot` of the survivors
+// (none in 7 slices of 8 at the usual 0.2 %) -> slots in the WAVE's own LDS list by prefix count, the list's length a scalar
+// -- no atomic, no memory round trip inside the MFMA loop (a first version appended straight to the per-query lists: 34
+// `s_waitcnt vmcnt(0)` in the loop, each draining the fragment ring, and 268 registers = one wave per SIMD).  The list
+// (about 130 entries over a wave's life at k = 100) is flushed to the per-query lists in HBM when it could overflow and at
+// the end: one returning atomic per entry, 64 entries per wait.
+constexpr int kKnnMaxChunk = 4096;   // query rows per chunk (qinco_knn_search): thresholds in LDS
+constexpr int kKnnWaveList = 512;    // entries of a wave's survivor list (room for 4 x 64 checked once per 8 query rows)
+
+template <int D, bool FILT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 128 ? 2 : 1)))
 knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qnorm, int nqblocks,
-                 const float* __restrict__ db, long N, float* __restrict__ table, long ldt) {
+                 const float* __restrict__ db, long N, long row_stride, float* __restrict__ table, long ldt, KnnFilt f) {
   constexpr int NDB = D / 32;
+  if (!FILT && f.pred && *f.pred == 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
+  __shared__ unsigned s_tau[FILT ? kKnnMaxChunk : 1];
+  __shared__ unsigned long long s_key[FILT ? 4 : 1][FILT ? kKnnWaveList : 1];
+  __shared__ unsigned s_row[FILT ? 4 : 1][FILT ? kKnnWaveList : 1];
+  if constexpr (FILT) {
+    for (int i = threadIdx.x; i < nqblocks * 32; i += 256) s_tau[i] = f.tau[i];
+    __syncthreads();
+  }
   const long n0 = ((long)blockIdx.x * 4 + wave) * 32;
   if (n0 >= N) return;
   long row = n0 + j;
   const bool valid = row < N;
   if (!valid) row = N - 1;
-  const float* xp = db + row * D + half * 4;
+  const float* xp = db + row * row_stride * D + half * 4;
   f32x16 xt[NDB];
   float xn = 0.f;
 #pragma unroll
@@ -88,6 +138,18 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
 #pragma unroll
   for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
   float* tp = table + n0 + j;
+  int lcount = 0;  // entries of this wave's survivor list (uniform)
+  auto flush = [&]() __attribute__((always_inline)) {
+    if constexpr (FILT) {
+      for (int i = lane; i < lcount; i += 64) {  // this wave's own DS writes, in order: no barrier
+        const unsigned long long key = s_key[wave][i];
+        const unsigned qrow = s_row[wave][i];
+        const unsigned pos = atomicAdd(f.cnt + qrow, 1u);
+        if (pos < (unsigned)kKnnCap) f.cand[(long)qrow * kKnnCap + pos] = key;
+      }
+      lcount = 0;
+    }
+  };
   auto block = [&](const int qb) __attribute__((always_inline)) {
     f32x16 acc;
 #pragma unroll
@@ -113,7 +175,30 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
     }
     wp += NF * 64;
     // lane holds queries qb*32 + 8g + 4*half + e of database row n0 + j
-    if (valid) {
+    if constexpr (FILT) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int base = qb * 32 + 8 * g + 4 * half;
+        const uint4 tk = *reinterpret_cast<const uint4*>(&s_tau[base]);
+        if (lcount + 256 > kKnnWaveList) flush();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = __fsub_rn(__fadd_rn(qn[g][e], xn), __fmul_rn(2.f, acc[4 * g + e]));
+          const unsigned u = knn_key_hi(d);
+          const unsigned t = e == 0 ? tk.x : e == 1 ? tk.y : e == 2 ? tk.z : tk.w;
+          const bool pass = valid && u <= t && base + e < f.nq_valid;
+          const unsigned long long m = __ballot(pass);
+          if (m) {  // uniform
+            if (pass) {
+              const int p = lcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+              s_key[wave][p] = ((unsigned long long)u << 32) | (unsigned)(n0 + j);
+              s_row[wave][p] = (unsigned)(base + e);
+            }
+            lcount += __popcll(m);
+          }
+        }
+      }
+    } else if (valid) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int base = qb * 32 + 8 * g + 4 * half;
@@ -133,19 +218,14 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
     for (; qb < nqblocks; ++qb) block(qb);
   }
   if (qb < nqblocks) block(qb);
+  flush();
 }
 
 // ---------------------------------------------------------------------------------------------
 // selection
 // ---------------------------------------------------------------------------------------------
-constexpr int kKnnCap = 8192;      // LDS candidate buffer (64 KiB of 64-bit keys)
-constexpr int kKnnThreads = 1024;
-constexpr int kKnnMaxK = 2048;
-
 __device__ __forceinline__ unsigned long long knn_key(float d, unsigned idx) {
-  unsigned u = __builtin_bit_cast(unsigned, d);
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> unsigned (NaNs sort last)
-  return ((unsigned long long)u << 32) | idx;
+  return ((unsigned long long)knn_key_hi(d) << 32) | idx;
 }
 __device__ __forceinline__ float knn_key_dist(unsigned long long key) {
   unsigned u = (unsigned)(key >> 32);
@@ -153,14 +233,53 @@ __device__ __forceinline__ float knn_key_dist(unsigned long long key) {
   return __builtin_bit_cast(float, u);
 }
 
-// table: (nq, ldt) fp32, row q holds N distances.  ids_out (nq, k) int64, dist_out (nq, k) fp32 or nullptr.
+// buf[0 .. count) unsorted keys in LDS (count <= kKnnCap, a barrier behind the last write): bitonic sort, the first k emitted
+__device__ __forceinline__ void knn_sort_emit(unsigned long long* buf, int count, int k, long q, long long* __restrict__ ids_out,
+                                              float* __restrict__ dist_out, unsigned* __restrict__ tau_out) {
+  const int tid = threadIdx.x;
+  int n2 = 64;
+  while (n2 < count) n2 <<= 1;
+  for (int i = count + tid; i < n2; i += kKnnThreads) buf[i] = ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < n2 / 2; t += kKnnThreads) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = buf[lo], b = buf[hi];
+        if ((a > b) == up) {
+          buf[lo] = b;
+          buf[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tau_out) {  // the sample pass of the filtered form: only the k-th key's high word is wanted
+    if (tid == 0) tau_out[q] = (unsigned)(buf[k - 1] >> 32);
+    return;
+  }
+  for (int i = tid; i < k; i += kKnnThreads) {
+    const unsigned long long key = buf[i];
+    ids_out[q * k + i] = (long long)(key & 0xffffffffull);
+    if (dist_out) dist_out[q * k + i] = knn_key_dist(key);
+  }
+}
+
+// table: (nq, ldt) fp32, row q holds N distances.  ids_out (nq, k) int64, dist_out (nq, k) fp32 or nullptr -- or, with tau_out
+// (the sample pass of the filtered form), tau_out[q] = high word of the k-th smallest key and cnt_out[q] = 0, nothing else.
+// pred: nullptr or the chunk's fall-back flag (run only if set).
 __global__ void __launch_bounds__(kKnnThreads)
 knn_select_kernel(const float* __restrict__ table, long ldt, long N, int k, long long* __restrict__ ids_out,
-                  float* __restrict__ dist_out) {
+                  float* __restrict__ dist_out, unsigned* __restrict__ tau_out, unsigned* __restrict__ cnt_out,
+                  const int* __restrict__ pred) {
   __shared__ unsigned hist[4096];
   __shared__ unsigned long long buf[kKnnCap];
   __shared__ unsigned s_ub, s_bucket, s_before, s_cnt, s_count;
   const int tid = threadIdx.x;
+  if (pred && *pred == 0) return;
+  if (cnt_out && tid == 0) cnt_out[blockIdx.x] = 0;
   const float* row = table + (long)blockIdx.x * ldt;
 
   unsigned long long prefix = 0;  // the k-th key starts with these `pbits` bits
@@ -247,31 +366,26 @@ knn_select_kernel(const float* __restrict__ table, long ldt, long N, int k, long
     }
   }
   __syncthreads();
-  const int count = (int)s_count;
-  int n2 = 64;
-  while (n2 < count) n2 <<= 1;
-  for (int i = count + tid; i < n2; i += kKnnThreads) buf[i] = ~0ull;
+  knn_sort_emit(buf, (int)s_count, k, (long)blockIdx.x, ids_out, dist_out, tau_out);
+}
+
+// The filtered form's selection: query row q's candidate list (cnt[q] keys, every key <= tau[q], the k smallest among them)
+// -> sorted in LDS, the first k emitted.  An overflowed list (cnt > kKnnCap) or one with fewer than k keys raises *ovf:
+// the predicated unfiltered kernels behind this launch redo the whole chunk.
+__global__ void __launch_bounds__(kKnnThreads)
+knn_cand_select_kernel(const unsigned long long* __restrict__ cand, const unsigned* __restrict__ cnt, int k,
+                       long long* __restrict__ ids_out, float* __restrict__ dist_out, int* __restrict__ ovf) {
+  __shared__ unsigned long long buf[kKnnCap];
+  const int tid = threadIdx.x;
+  const unsigned count = cnt[blockIdx.x];
+  if (count > (unsigned)kKnnCap || count < (unsigned)k) {
+    if (tid == 0) atomicOr(ovf, 1);
+    return;
+  }
+  const unsigned long long* src = cand + (long)blockIdx.x * kKnnCap;
+  for (unsigned i = tid; i < count; i += kKnnThreads) buf[i] = src[i];
   __syncthreads();
-  for (int size = 2; size <= n2; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < n2 / 2; t += kKnnThreads) {
-        const int lo = 2 * t - (t & (stride - 1));
-        const int hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const unsigned long long a = buf[lo], b = buf[hi];
-        if ((a > b) == up) {
-          buf[lo] = b;
-          buf[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = tid; i < k; i += kKnnThreads) {
-    const unsigned long long key = buf[i];
-    ids_out[(long)blockIdx.x * k + i] = (long long)(key & 0xffffffffull);
-    if (dist_out) dist_out[(long)blockIdx.x * k + i] = knn_key_dist(key);
-  }
+  knn_sort_emit(buf, (int)count, k, (long)blockIdx.x, ids_out, dist_out, nullptr);
 }
 
 // sum over count elements of (a - b)^2, fp64 accumulation (AnyVectMSE.update, reference qinco/metrics.py:43-50)

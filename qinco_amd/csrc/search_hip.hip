@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 #include "abi_util.hpp"
 #include "knn_kernel.hpp"
@@ -20,6 +21,16 @@ struct qinco_knn_s {
   size_t q_rows = 0;         // chunk capacity in query rows (multiple of 32)
   float* table = nullptr;
   size_t table_elems = 0;
+  // the filtered form (knn_kernel.hpp): per-chunk candidate lists, thresholds, counters, and one fall-back flag per chunk
+  unsigned long long* cand = nullptr;
+  size_t cand_bytes = 0;
+  unsigned* tau = nullptr;   // [chunk] thresholds, then [chunk] counters
+  size_t tau_bytes = 0;
+  int* ovf = nullptr;
+  size_t ovf_bytes = 0;
+  long last_chunks = 0, last_filtered = 0;   // of the last search: chunks, chunks that took the filtered form
+  int filter_mode = 1;       // 0: never, 1: where it pays (n >= filter_min_n and a sampling stride >= 4)
+  long filter_min_n = 65536;
   // staging for the host form
   void* s_db = nullptr;
   size_t s_db_bytes = 0;
@@ -59,16 +70,64 @@ extern "C" int qinco_knn_create(int32_t D, qinco_knn* out) {
 extern "C" int qinco_knn_destroy(qinco_knn s) {
   if (!s) return QINCO_OK;
   (void)hipDeviceSynchronize();
-  for (void* p : {(void*)s->qstream, (void*)s->qnorm, (void*)s->table, s->s_db, s->s_q, s->s_ids, s->s_dist})
+  for (void* p : {(void*)s->qstream, (void*)s->qnorm, (void*)s->table, (void*)s->cand, (void*)s->tau, (void*)s->ovf, s->s_db, s->s_q,
+                  s->s_ids, s->s_dist})
     if (p) (void)hipFree(p);
   delete s;
   return QINCO_OK;
 }
 
 template <int D>
-static void launch_table(qinco_knn_s* s, int nqblocks, const float* db, long n, long ldt, hipStream_t st) {
-  hipLaunchKernelGGL(knn_table_kernel<D>, dim3((unsigned)((n + 127) / 128)), dim3(256), 0, st, s->qstream, s->qnorm, nqblocks, db,
-                     n, s->table, ldt);
+static void launch_table_d(qinco_knn_s* s, int nqblocks, const float* db, long n, long stride, long ldt, bool filt, const KnnFilt& f,
+                           hipStream_t st) {
+  const dim3 grid((unsigned)((n + 127) / 128));
+  if (filt)
+    hipLaunchKernelGGL((knn_table_kernel<D, true>), grid, dim3(256), 0, st, s->qstream, s->qnorm, nqblocks, db, n, stride, s->table, ldt, f);
+  else
+    hipLaunchKernelGGL((knn_table_kernel<D, false>), grid, dim3(256), 0, st, s->qstream, s->qnorm, nqblocks, db, n, stride, s->table, ldt, f);
+}
+
+// columns 0 .. n-1 of the table = database rows 0, stride, 2 stride, ...
+static int launch_table(qinco_knn_s* s, int nqblocks, const float* db, long n, long stride, long ldt, bool filt, const KnnFilt& f,
+                        hipStream_t st) {
+  switch (s->D) {
+    case 32: launch_table_d<32>(s, nqblocks, db, n, stride, ldt, filt, f, st); break;
+    case 64: launch_table_d<64>(s, nqblocks, db, n, stride, ldt, filt, f, st); break;
+    case 96: launch_table_d<96>(s, nqblocks, db, n, stride, ldt, filt, f, st); break;
+    case 128: launch_table_d<128>(s, nqblocks, db, n, stride, ldt, filt, f, st); break;
+    case 256: launch_table_d<256>(s, nqblocks, db, n, stride, ldt, filt, f, st); break;
+    case 768: launch_table_d<768>(s, nqblocks, db, n, stride, ldt, filt, f, st); break;
+    default: return fail(QINCO_ERR_UNSUPPORTED, "no table kernel instance for D=%d", s->D);
+  }
+  HIP_TRY(hipGetLastError());
+  return QINCO_OK;
+}
+
+extern "C" int qinco_knn_set_option(qinco_knn s, int32_t option, int64_t value) {
+  if (!s) return fail(QINCO_ERR_INVALID, "qinco_knn_set_option: null handle");
+  switch (option) {
+    case QINCO_KNN_OPT_FILTER: s->filter_mode = value != 0; return QINCO_OK;
+    case QINCO_KNN_OPT_FILTER_MIN_N:
+      if (value < 1) return fail(QINCO_ERR_INVALID, "qinco_knn_set_option: filter_min_n must be >= 1");
+      s->filter_min_n = (long)value;
+      return QINCO_OK;
+    default: return fail(QINCO_ERR_INVALID, "qinco_knn_set_option: unknown option %d", (int)option);
+  }
+}
+
+extern "C" int qinco_knn_last_stats(qinco_knn s, int64_t* out3) {
+  if (!s || !out3) return fail(QINCO_ERR_INVALID, "qinco_knn_last_stats: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipDeviceSynchronize());
+  out3[0] = s->last_chunks;
+  out3[1] = s->last_filtered;
+  out3[2] = 0;
+  if (s->last_filtered > 0) {
+    std::vector<int> h((size_t)s->last_chunks);
+    HIP_TRY(hipMemcpy(h.data(), s->ovf, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int v : h) out3[2] += v != 0;
+  }
+  return QINCO_OK;
 }
 
 extern "C" int qinco_knn_search(qinco_knn s, const float* db, int64_t n, const float* queries, int64_t nq, int32_t k,
@@ -85,7 +144,7 @@ extern "C" int qinco_knn_search(qinco_knn s, const float* db, int64_t n, const f
   // chunk of queries: table of at most 8 GiB (the card has 288 GB; the database is re-read once per chunk)
   long chunk = (long)(((size_t)8 << 30) / ((size_t)ldt * 4)) / 32 * 32;
   if (chunk < 32) chunk = 32;
-  if (chunk > 4096) chunk = 4096;
+  if (chunk > kKnnMaxChunk) chunk = kKnnMaxChunk;
   // every wave loops over the whole query stream: keep it L2-resident (4 MiB per XCD), about 1 MiB
   const long l2_rows = ((long)1 << 20) / (D * 4) / 32 * 32;
   if (chunk > l2_rows) chunk = l2_rows;
@@ -110,25 +169,54 @@ extern "C" int qinco_knn_search(qinco_knn s, const float* db, int64_t n, const f
     if ((rc = grow((void**)&s->table, &bytes, (size_t)chunk * ldt * sizeof(float)))) return rc;
     s->table_elems = bytes / sizeof(float);
   }
-  for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+  // The filtered form (knn_kernel.hpp): sampling stride so that a query expects about kKnnCap / 4 candidates (k * stride of them
+  // on exchangeable data); below a stride of 4 the sample pass costs more than the table it saves.
+  long stride = (long)kKnnCap / (4 * (long)k);
+  if (stride > 32) stride = 32;
+  const bool filtered = s->filter_mode != 0 && n >= s->filter_min_n && stride >= 4 && (n + stride - 1) / stride >= k;
+  const long ns = filtered ? (long)((n + stride - 1) / stride) : 0;   // sample rows 0, stride, 2 stride, ...
+  const long lds_ = (ns + 31) / 32 * 32;
+  const long nchunks = (long)((nq + chunk - 1) / chunk);
+  if (filtered) {
+    if ((rc = grow((void**)&s->cand, &s->cand_bytes, (size_t)chunk * kKnnCap * sizeof(unsigned long long)))) return rc;
+    if ((rc = grow((void**)&s->tau, &s->tau_bytes, (size_t)chunk * 2 * sizeof(unsigned)))) return rc;
+    if ((rc = grow((void**)&s->ovf, &s->ovf_bytes, (size_t)nchunks * sizeof(int)))) return rc;
+    HIP_TRY(hipMemsetAsync(s->ovf, 0, (size_t)nchunks * sizeof(int), st));
+  }
+  s->last_chunks = nchunks;
+  s->last_filtered = filtered ? nchunks : 0;
+  long ci = 0;
+  for (int64_t q0 = 0; q0 < nq; q0 += chunk, ++ci) {
     const long cq = (nq - q0 < chunk) ? (long)(nq - q0) : chunk;
     const long nqb = (cq + 31) / 32;
     long g = (nqb * 32 * (D / 4) + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(knn_pack_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, queries + q0 * D, cq, D, s->qstream, s->qnorm, nqb);
     HIP_TRY(hipGetLastError());
-    switch (D) {
-      case 32: launch_table<32>(s, (int)nqb, db, n, ldt, st); break;
-      case 64: launch_table<64>(s, (int)nqb, db, n, ldt, st); break;
-      case 96: launch_table<96>(s, (int)nqb, db, n, ldt, st); break;
-      case 128: launch_table<128>(s, (int)nqb, db, n, ldt, st); break;
-      case 256: launch_table<256>(s, (int)nqb, db, n, ldt, st); break;
-      case 768: launch_table<768>(s, (int)nqb, db, n, ldt, st); break;
-      default: return fail(QINCO_ERR_UNSUPPORTED, "no table kernel instance for D=%d", D);
+    long long* ids_q = reinterpret_cast<long long*>(ids_out) + q0 * k;
+    float* dist_q = dist_out ? dist_out + q0 * k : nullptr;
+    KnnFilt f{};
+    if (filtered) {
+      unsigned* cnt = s->tau + chunk;
+      // (1) thresholds from the sample  (2) the whole table, survivors appended  (3) each query's candidates sorted
+      if ((rc = launch_table(s, (int)nqb, db, ns, stride, lds_, false, f, st))) return rc;
+      hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)cq), dim3(kKnnThreads), 0, st, s->table, lds_, ns, (int)k, nullptr,
+                         nullptr, s->tau, cnt, nullptr);
+      HIP_TRY(hipGetLastError());
+      f.tau = s->tau;
+      f.cnt = cnt;
+      f.cand = s->cand;
+      f.nq_valid = (int)cq;
+      if ((rc = launch_table(s, (int)nqb, db, (long)n, 1, ldt, true, f, st))) return rc;
+      hipLaunchKernelGGL(knn_cand_select_kernel, dim3((unsigned)cq), dim3(kKnnThreads), 0, st, s->cand, cnt, (int)k, ids_q, dist_q,
+                         s->ovf + ci);
+      HIP_TRY(hipGetLastError());
+      f = KnnFilt{};
+      f.pred = s->ovf + ci;   // the unfiltered kernels below run only if a list overflowed (or came up short)
     }
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)cq), dim3(kKnnThreads), 0, st, s->table, ldt, (long)n, (int)k,
-                       reinterpret_cast<long long*>(ids_out) + q0 * k, dist_out ? dist_out + q0 * k : nullptr);
+    if ((rc = launch_table(s, (int)nqb, db, (long)n, 1, ldt, false, f, st))) return rc;
+    hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)cq), dim3(kKnnThreads), 0, st, s->table, ldt, (long)n, (int)k, ids_q, dist_q,
+                       nullptr, nullptr, f.pred);
     HIP_TRY(hipGetLastError());
   }
   return QINCO_OK;

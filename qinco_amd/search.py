@@ -20,11 +20,23 @@ F32 = np.float32
 class KnnSearcher:
     """ids[q] = argsort_n(|queries[q]|^2 + |db[n]|^2 - 2 queries[q].db[n])[:k]  (stable: ties -> lower n)."""
 
-    def __init__(self, D: int):
+    def __init__(self, D: int, filtered: bool = True, filter_min_n: int | None = None):
+        """filtered: large databases take the form that never writes the (queries x n) distance table (csrc/knn_kernel.hpp;
+        the same ids and distances bit for bit); filter_min_n: the smallest n that takes it (library default 65536)."""
         self.lib = _lib.load()
         self.D = int(D)
         self._h = C.c_void_p()
         _lib.check(self.lib.qinco_knn_create(self.D, C.byref(self._h)))
+        _lib.check(self.lib.qinco_knn_set_option(self._h, 0, int(bool(filtered))))
+        if filter_min_n is not None:
+            _lib.check(self.lib.qinco_knn_set_option(self._h, 1, int(filter_min_n)))
+
+    def last_stats(self) -> dict:
+        """Of the last search (synchronises the device): chunks of queries, those that took the filtered form, those redone
+        unfiltered because a candidate list overflowed."""
+        out = (C.c_int64 * 3)()
+        _lib.check(self.lib.qinco_knn_last_stats(self._h, out))
+        return {"chunks": int(out[0]), "filtered": int(out[1]), "redone_unfiltered": int(out[2])}
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

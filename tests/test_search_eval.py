@@ -154,6 +154,76 @@ def test_knn_exact_ties_resolve_to_lower_index_and_radix_refinement():
     knn.close()
 
 
+def _knn_both_forms(D, db, q, k, min_n=1024):
+    """The same search through the filtered form (forced from min_n rows on) and the unfiltered form: ids and distances."""
+    import torch
+    from qinco_amd.search import KnnSearcher
+    dbt, qt = torch.from_numpy(db).cuda(), torch.from_numpy(q).cuda()
+    out = []
+    for filtered in (True, False):
+        knn = KnnSearcher(D, filtered=filtered, filter_min_n=min_n)
+        ids, dist = knn.search(dbt, qt, k=k, return_dist=True)
+        st = knn.last_stats()
+        out.append((ids.cpu().numpy(), dist.cpu().numpy(), st))
+        knn.close()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,N,Q,k", [(128, 150_001, 70, 100), (32, 70_000, 4200, 10), (768, 66_000, 33, 100), (96, 20_000, 40, 600),
+                                     (64, 9_000, 5, 1), (256, 131_072, 64, 200)])
+def test_knn_filtered_form_is_bit_identical_to_the_table_form(D, N, Q, k):
+    """Round 5: large databases never write the (queries x n) table -- thresholds from a strided sample, survivors of the whole
+    table appended to per-query lists, those sorted (csrc/knn_kernel.hpp).  Same ids, same distance bits as the unfiltered
+    kernels, and against the oracle's stable argsort on a few rows."""
+    from oracle.qinco_oracle import approx_pairwise_distance
+    rs = np.random.RandomState(D + N + k)
+    db = rs.randn(N, D).astype(np.float32)
+    q = (db[rs.choice(N, Q)] + 0.5 * rs.randn(Q, D)).astype(np.float32)
+    (ids_f, dist_f, st_f), (ids_t, dist_t, st_t) = _knn_both_forms(D, db, q, k)
+    assert st_t["filtered"] == 0
+    stride = min(32, 8192 // (4 * k))
+    if stride >= 4:
+        assert st_f["filtered"] == st_f["chunks"] >= 1 and st_f["redone_unfiltered"] == 0, st_f
+    else:
+        assert st_f["filtered"] == 0, st_f       # k = 600: the sample would cost more than the table it saves
+    assert np.array_equal(ids_f, ids_t) and np.array_equal(dist_f.view(np.uint32), dist_t.view(np.uint32))
+    rows = rs.choice(Q, min(Q, 8), replace=False)
+    d = approx_pairwise_distance(q[rows], db)
+    order = np.argsort(d, axis=1, kind="stable")
+    want_sorted = np.take_along_axis(d, order[:, :k + 1], axis=1)
+    _check_shortlists(ids_f[rows], dist_f[rows], order[:, :k].astype(np.int64), want_sorted)
+
+
+@pytest.mark.gpu
+def test_knn_filtered_form_falls_back_on_the_device_when_a_list_overflows():
+    """Adversarial data for the filter: 4 distinct rows, 20 000 copies each -- every copy of the nearest row sits exactly AT the
+    threshold, 20 000 candidates for 8192 slots.  The chunk's flag is raised and the unfiltered kernels queued behind it redo
+    the chunk: the stable order (lower id first) must come out; a clustered database in sorted order (a sample that is
+    unrepresentative row-prefix-wise but fine strided) stays on the filtered form."""
+    rs = np.random.RandomState(5)
+    D, N = 32, 80_000
+    base = rs.randn(4, D).astype(np.float32)
+    db = np.repeat(base, N // 4, axis=0)
+    q = base[[2, 0]] + 0.01
+    (ids_f, dist_f, st_f), (ids_t, dist_t, st_t) = _knn_both_forms(D, db, q, 50)
+    assert st_f == {"chunks": 1, "filtered": 1, "redone_unfiltered": 1}, st_f
+    assert np.array_equal(ids_f[0], np.arange(40000, 40050)) and np.array_equal(ids_f[1], np.arange(50))
+    assert np.array_equal(ids_f, ids_t) and np.array_equal(dist_f.view(np.uint32), dist_t.view(np.uint32))
+    # clustered and sorted by cluster: 64 clusters of 2000 rows; queries near cluster centres
+    centres = 4.0 * rs.randn(64, D).astype(np.float32)
+    db = (np.repeat(centres, 2000, axis=0) + 0.3 * rs.randn(128_000, D)).astype(np.float32)
+    q = (centres[rs.choice(64, 40)] + 0.3 * rs.randn(40, D)).astype(np.float32)
+    (ids_f, dist_f, st_f), (ids_t, dist_t, _) = _knn_both_forms(D, db, q, 100)
+    assert st_f["filtered"] == 1 and st_f["redone_unfiltered"] == 0, st_f
+    assert np.array_equal(ids_f, ids_t) and np.array_equal(dist_f.view(np.uint32), dist_t.view(np.uint32))
+    # NaN in the database (a corrupt row): both forms order keys the same way
+    db[777] = np.nan
+    db[780] = np.nan                                  # 780 is a row of the strided sample (stride 20), 777 is not
+    (ids_f, dist_f, _), (ids_t, dist_t, _) = _knn_both_forms(D, db, q, 100)
+    assert np.array_equal(ids_f, ids_t) and np.array_equal(dist_f.view(np.uint32), dist_t.view(np.uint32))
+
+
 @pytest.mark.gpu
 def test_knn_argument_errors_and_empty():
     from qinco_amd.search import KnnSearcher

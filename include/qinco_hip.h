@@ -267,6 +267,7 @@ QINCO_API int qinco_knn_search(qinco_knn knn, const float* db, int64_t n, const 
  * the filtered form, chunks that were redone unfiltered}. */
 #define QINCO_KNN_OPT_FILTER 0
 #define QINCO_KNN_OPT_FILTER_MIN_N 1
+#define QINCO_KNN_OPT_QUERY_BYTES 2   /* bytes of query rows per chunk (default 1 MiB: the chunk's fragments stay in L2), <= 4096 rows */
 QINCO_API int qinco_knn_set_option(qinco_knn knn, int32_t option, int64_t value);
 QINCO_API int qinco_knn_last_stats(qinco_knn knn, int64_t* out3);
 /* the same on host buffers; synchronous */

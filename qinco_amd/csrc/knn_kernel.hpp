@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mlp_args.hpp"
 
 namespace qinco {
@@ -102,11 +104,13 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
   if (!FILT && f.pred && *f.pred == 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
-  __shared__ unsigned s_tau[FILT ? kKnnMaxChunk : 1];
+  __shared__ uint2 s_qt[FILT ? kKnnMaxChunk : 1];   // per query row of the chunk: (|q|^2 bits, threshold key); rows >= nq_valid: (0, 0)
   __shared__ unsigned long long s_key[FILT ? 4 : 1][FILT ? kKnnWaveList : 1];
   __shared__ unsigned s_row[FILT ? 4 : 1][FILT ? kKnnWaveList : 1];
   if constexpr (FILT) {
-    for (int i = threadIdx.x; i < nqblocks * 32; i += 256) s_tau[i] = f.tau[i];
+    // a padding row's fragments and norm are 0: its distances are |x|^2 >= 0, keys >= 0x80000000 -- above a threshold of 0
+    for (int i = threadIdx.x; i < nqblocks * 32; i += 256)
+      s_qt[i] = make_uint2(__builtin_bit_cast(unsigned, qnorm[i]), i < f.nq_valid ? f.tau[i] : 0u);
     __syncthreads();
   }
   const long n0 = ((long)blockIdx.x * 4 + wave) * 32;
@@ -175,30 +179,7 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
     }
     wp += NF * 64;
     // lane holds queries qb*32 + 8g + 4*half + e of database row n0 + j
-    if constexpr (FILT) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int base = qb * 32 + 8 * g + 4 * half;
-        const uint4 tk = *reinterpret_cast<const uint4*>(&s_tau[base]);
-        if (lcount + 256 > kKnnWaveList) flush();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float d = __fsub_rn(__fadd_rn(qn[g][e], xn), __fmul_rn(2.f, acc[4 * g + e]));
-          const unsigned u = knn_key_hi(d);
-          const unsigned t = e == 0 ? tk.x : e == 1 ? tk.y : e == 2 ? tk.z : tk.w;
-          const bool pass = valid && u <= t && base + e < f.nq_valid;
-          const unsigned long long m = __ballot(pass);
-          if (m) {  // uniform
-            if (pass) {
-              const int p = lcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-              s_key[wave][p] = ((unsigned long long)u << 32) | (unsigned)(n0 + j);
-              s_row[wave][p] = (unsigned)(base + e);
-            }
-            lcount += __popcll(m);
-          }
-        }
-      }
-    } else if (valid) {
+    if (valid) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int base = qb * 32 + 8 * g + 4 * half;
@@ -208,17 +189,88 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
       }
     }
   };
-  int qb = 0;  // two blocks per trip (where the registers allow it): see ivf_assign_kernel
-  if constexpr (NDB <= 8) {
-    for (; qb + 1 < nqblocks; qb += 2) {
-      block(qb);
-      block(qb + 1);
+  if constexpr (FILT) {
+    // Software pipeline inside the wave: while block qb's MFMA chain runs, the VALU filters block qb - 1's tile out of the
+    // other accumulator, one (query, 32 rows) slice behind every 64 / NF-th of the chain.  (First version: the filter behind
+    // its own block's chain -- the two waves of a SIMD start together and stay in step, so both were in their MFMA phase,
+    // then both in their ~700-instruction filter phase with the matrix pipe idle: 0.68 of the pipe at D = 128.)
+    auto filt = [&](const f32x16& prev, const int pq, const int v) __attribute__((always_inline)) {
+      const int g = v >> 2, e = v & 3;
+      const int qrow = pq * 32 + 8 * g + 4 * half + e;
+      if (e == 0 && lcount + 256 > kKnnWaveList) flush();
+      const uint2 qt = s_qt[qrow];
+      const float d = __fsub_rn(__fadd_rn(__builtin_bit_cast(float, qt.x), xn), __fmul_rn(2.f, prev[v]));
+      const unsigned u = knn_key_hi(d);
+      const bool pass = valid && u <= qt.y;
+      const unsigned long long m = __ballot(pass);
+      if (m) {  // uniform
+        if (pass) {
+          const int p = lcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          s_key[wave][p] = ((unsigned long long)u << 32) | (unsigned)(n0 + j);
+          s_row[wave][p] = (unsigned)qrow;
+        }
+        lcount += __popcll(m);
+      }
+    };
+    auto blockp = [&](const int qb, f32x16& acc, const f32x16& prev, auto have_prev) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < NDB; ++ib) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = ib * 4 + q;
+          const f32x4 w = ring[i % P];
+          ring[i % P] = wp[(i + P) * 64];
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], xt[ib][4 * q + e], acc, 0, 0, 0);
+          if constexpr (decltype(have_prev)::value) {
+#pragma unroll
+            for (int v = (i * 16) / NF; v < ((i + 1) * 16) / NF; ++v) filt(prev, qb - 1, v);
+          }
+        }
+      }
+      wp += NF * 64;
+    };
+    f32x16 acc0, acc1 = {};
+    if constexpr (NDB <= 8) {
+      blockp(0, acc0, acc1, std::false_type{});
+      int qb = 1;
+      for (; qb + 1 < nqblocks; qb += 2) {
+        blockp(qb, acc1, acc0, std::true_type{});
+        blockp(qb + 1, acc0, acc1, std::true_type{});
+      }
+      if (qb < nqblocks) {
+        blockp(qb, acc1, acc0, std::true_type{});
+#pragma unroll
+        for (int v = 0; v < 16; ++v) filt(acc1, qb, v);
+      } else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) filt(acc0, qb - 1, v);
+      }
+    } else {  // D = 768: 384 registers of database rows leave no room for a second accumulator (12 spilled): filter behind the chain
+      for (int qb = 0; qb < nqblocks; ++qb) {
+        blockp(qb, acc0, acc1, std::false_type{});
+#pragma unroll
+        for (int v = 0; v < 16; ++v) filt(acc0, qb, v);
+      }
     }
+    flush();
   } else {
-    for (; qb < nqblocks; ++qb) block(qb);
+    int qb = 0;  // two blocks per trip (where the registers allow it): see ivf_assign_kernel
+    if constexpr (NDB <= 8) {
+      for (; qb + 1 < nqblocks; qb += 2) {
+        block(qb);
+        block(qb + 1);
+      }
+    } else {
+      for (; qb < nqblocks; ++qb) block(qb);
+    }
+    if (qb < nqblocks) block(qb);
   }
-  if (qb < nqblocks) block(qb);
-  flush();
 }
 
 // ---------------------------------------------------------------------------------------------

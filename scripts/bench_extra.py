@@ -4,6 +4,7 @@ BASELINE.json workload (C1..C4), greedy and beam, with the fused-MLP kernel's ro
 per (workload, mode).  Usage: python scripts/bench_extra.py [C1 C2 ...] [--batch N] [--steps K]"""
 import argparse
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -122,6 +123,8 @@ def knn_rate():
         got = {}
         for filtered in (True, False):
             knn = KnnSearcher(D, filtered=filtered)
+            if os.environ.get("KNN_QUERY_BYTES"):
+                knn.lib.qinco_knn_set_option(knn._h, 2, int(os.environ["KNN_QUERY_BYTES"]))
             knn.search(db, q, k=100)   # warm-up at the full shape (allocates the scratch)
             torch.cuda.synchronize()
             best = 1e9

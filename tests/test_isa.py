@@ -182,6 +182,23 @@ def test_support_kernels_have_no_scratch(kernels):
         assert k.meta[".vgpr_count"] <= 512
 
 
+def test_filtered_search_table_kernel_keeps_its_plan(kernels):
+    """knn_table_kernel<D, true> (the small-db search's filtered form): two waves per SIMD up to D = 128 (<= 256 registers, two
+    workgroups' LDS within a CU's 160 KiB); the survivors go to the wave's LDS list by ballot + prefix count, so the only global
+    atomics are the flush's (one inlined copy per 8 query rows of a block + the final one: 21), never one per (query, 32 rows) slice, and the MFMA loop holds
+    no returning atomic in front of every slice -- the first version's 34 `s_waitcnt vmcnt(0)` in the loop."""
+    for D in (32, 64, 96, 128):
+        k = kernels[f"knn_table_kernel<{D},true>"]
+        assert k.meta[".vgpr_count"] <= 256 and k.meta[".group_segment_fixed_size"] <= 80 * 1024, (D, k.meta)
+        atomics = sum(x.startswith("global_atomic_add") for x in k.text)
+        assert 1 <= atomics <= 24, (D, atomics)                    # (one per slice would be 16 per inlined block: 80)
+        assert sum(x.startswith(("ds_write_b64", "ds_write2_b32", "ds_write2st64_b32")) for x in k.text) >= 16    # the wave-list appends
+    k = kernels["knn_table_kernel<128,true>"]
+    assert sum(isa.is_mfma(x) for x in k.text) == 64 * 4          # first block, two pipelined blocks per trip, remainder block
+    k = kernels["knn_table_kernel<128,false>"]
+    assert sum(x.startswith("global_atomic") for x in k.text) == 0
+
+
 def test_pair_selection_runs_on_min_max_not_on_compare_and_select(kernels):
     """select.hpp pair_top_t: the 63 + 32 comparators of the bucket-minimum sort and the 63 + 32 of the 32-key sort are
     v_min / v_max pairs -- f32 for the threshold, f64 for the (distance, index) keys packed into a double's mantissa -- and the

@@ -196,6 +196,29 @@ def test_knn_filtered_form_is_bit_identical_to_the_table_form(D, N, Q, k):
 
 
 @pytest.mark.gpu
+def test_knn_filtered_form_at_the_reference_scale():
+    """bigann1M's shape (search_tasks.py:551-603: 10^6 reconstructions, D = 128, top-100) with 3000 queries -- two chunks of queries,
+    the second ragged: the filtered form (the default there) against the table form, every id and distance bit; no chunk redone."""
+    import torch
+    from qinco_amd.search import KnnSearcher
+    g = torch.Generator(device="cuda").manual_seed(3)
+    db = torch.randn(1_000_000, 128, device="cuda", generator=g)
+    q = db[torch.randint(0, 1_000_000, (3000,), device="cuda", generator=g)] + 0.7 * torch.randn(3000, 128, device="cuda", generator=g)
+    out = {}
+    for filtered in (True, False):
+        knn = KnnSearcher(128, filtered=filtered)
+        ids, dist = knn.search(db, q, k=100, return_dist=True)
+        out[filtered] = (ids, dist, knn.last_stats())
+        knn.close()
+    assert out[True][2] == {"chunks": 2, "filtered": 2, "redone_unfiltered": 0} and out[False][2]["filtered"] == 0
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1].view(torch.int32), out[False][1].view(torch.int32))
+    assert bool((out[True][1][:, 1:] >= out[True][1][:, :-1]).all())
+    # the nearest row of a query that is a perturbed database row is (almost always) that row: a sanity check on the ids themselves
+    d0 = ((db[out[True][0][:, 0]] - q) ** 2).sum(1)
+    assert torch.allclose(d0, out[True][1][:, 0], rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.gpu
 def test_knn_filtered_form_falls_back_on_the_device_when_a_list_overflows():
     """Adversarial data for the filter: 4 distinct rows, 20 000 copies each -- every copy of the nearest row sits exactly AT the
     threshold, 20 000 candidates for 8192 slots.  The chunk's flag is raised and the unfiltered kernels queued behind it redo

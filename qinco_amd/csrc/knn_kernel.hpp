@@ -75,6 +75,14 @@ __device__ __forceinline__ unsigned knn_key_hi(float d) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> unsigned (NaNs sort last)
 }
 
+// |q|^2 + |x|^2 - 2 q.x with the reference's roundings (utils.py:336-346); a NaN comes out as THE positive quiet NaN: which sign and
+// payload an fsub / fma hands on depends on the instruction form hipcc picks (a negated operand flips a NaN's sign), the two forms of
+// the search compile differently, and a negative NaN's key sorts FIRST -- the forms disagreed on corrupt rows one run in four.
+__device__ __forceinline__ float knn_dist(float qn, float xn, float dot) {
+  const float d = __fsub_rn(__fadd_rn(qn, xn), __fmul_rn(2.f, dot));
+  return d != d ? __builtin_bit_cast(float, 0x7fc00000u) : d;
+}
+
 // The filtered form's arguments (FILT = true); `pred` also predicates the unfiltered form when it runs as the fall-back.
 struct KnnFilt {
   const unsigned* tau;        // per query row of the chunk: high word of the k-th smallest key of the sample
@@ -94,7 +102,10 @@ struct KnnFilt {
 // (about 130 entries over a wave's life at k = 100) is flushed to the per-query lists in HBM when it could overflow and at
 // the end: one returning atomic per entry, 64 entries per wait.
 constexpr int kKnnMaxChunk = 4096;   // query rows per chunk (qinco_knn_search): thresholds in LDS
-constexpr int kKnnWaveList = 512;    // entries of a wave's survivor list (room for 4 x 64 checked once per 8 query rows)
+constexpr int kKnnWaveList = 512;    // entries of a wave's survivor list (room for 4 x 64 checked once per 8 query rows).
+// Two workgroups per CU = two waves per SIMD, measured: one wave per SIMD (lists of 2048 entries = 128 KiB of LDS) 27.4 -> 33.3 ms.
+// Per-wave cycle stamps (scripts/exp_knn_timeline.py): a wave needs ~545 cycles per 4-MFMA step of this loop (256 of matrix pipe)
+// when it has its SIMD nearly to itself in the launch's tail and ~640 when it shares it -- the pipe is 0.80 busy inside the loop.
 
 template <int D, bool FILT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 128 ? 2 : 1)))
@@ -104,7 +115,7 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
   if (!FILT && f.pred && *f.pred == 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
-  __shared__ uint2 s_qt[FILT ? kKnnMaxChunk : 1];   // per query row of the chunk: (|q|^2 bits, threshold key); rows >= nq_valid: (0, 0)
+  __shared__ uint2 s_qt[FILT ? kKnnMaxChunk + 32 : 1];   // per query row of the chunk: (|q|^2 bits, threshold key); rows >= nq_valid: (0, 0)
   __shared__ unsigned long long s_key[FILT ? 4 : 1][FILT ? kKnnWaveList : 1];
   __shared__ unsigned s_row[FILT ? 4 : 1][FILT ? kKnnWaveList : 1];
   if constexpr (FILT) {
@@ -185,7 +196,7 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
         const int base = qb * 32 + 8 * g + 4 * half;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          tp[(long)(base + e) * ldt] = __fsub_rn(__fadd_rn(qn[g][e], xn), __fmul_rn(2.f, acc[4 * g + e]));
+          tp[(long)(base + e) * ldt] = knn_dist(qn[g][e], xn, acc[4 * g + e]);
       }
     }
   };
@@ -194,20 +205,24 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
     // other accumulator, one (query, 32 rows) slice behind every 64 / NF-th of the chain.  (First version: the filter behind
     // its own block's chain -- the two waves of a SIMD start together and stay in step, so both were in their MFMA phase,
     // then both in their ~700-instruction filter phase with the matrix pipe idle: 0.68 of the pipe at D = 128.)
+    // (|q|^2, threshold) of the NEXT slice is read from LDS while the current one is filtered: a per-wave timeline of the first
+    // pipelined version showed 590 cycles per 4-MFMA step (256 ideal) with the slice's own `ds_read` + `lgkmcnt(0)` between the
+    // step's first and second MFMA -- in-order issue held the chain behind the LDS round trip.
+    uint2 qt_nxt = s_qt[4 * half];
     auto filt = [&](const f32x16& prev, const int pq, const int v) __attribute__((always_inline)) {
       const int g = v >> 2, e = v & 3;
-      const int qrow = pq * 32 + 8 * g + 4 * half + e;
+      const uint2* qp = s_qt + pq * 32 + 4 * half;
       if (e == 0 && lcount + 256 > kKnnWaveList) flush();
-      const uint2 qt = s_qt[qrow];
-      const float d = __fsub_rn(__fadd_rn(__builtin_bit_cast(float, qt.x), xn), __fmul_rn(2.f, prev[v]));
-      const unsigned u = knn_key_hi(d);
+      const uint2 qt = qt_nxt;
+      qt_nxt = v < 15 ? qp[8 * ((v + 1) >> 2) + ((v + 1) & 3)] : qp[32];   // (slice 0 of the next block; s_qt has a block of slack)
+      const unsigned u = knn_key_hi(knn_dist(__builtin_bit_cast(float, qt.x), xn, prev[v]));
       const bool pass = valid && u <= qt.y;
-      const unsigned long long m = __ballot(pass);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
       if (m) {  // uniform
         if (pass) {
           const int p = lcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
           s_key[wave][p] = ((unsigned long long)u << 32) | (unsigned)(n0 + j);
-          s_row[wave][p] = (unsigned)qrow;
+          s_row[wave][p] = (unsigned)(pq * 32 + 8 * g + 4 * half + e);
         }
         lcount += __popcll(m);
       }

@@ -243,7 +243,16 @@ def test_knn_filtered_form_falls_back_on_the_device_when_a_list_overflows():
     # NaN in the database (a corrupt row): both forms order keys the same way
     db[777] = np.nan
     db[780] = np.nan                                  # 780 is a row of the strided sample (stride 20), 777 is not
-    (ids_f, dist_f, _), (ids_t, dist_t, _) = _knn_both_forms(D, db, q, 100)
+    db[rs.choice(128_000, 300, replace=False), 5] = np.nan
+    (ids_f, dist_f, st_f), (ids_t, dist_t, _) = _knn_both_forms(D, db, q, 100)
+    assert st_f["redone_unfiltered"] == 0
+    assert np.array_equal(ids_f, ids_t) and np.array_equal(dist_f.view(np.uint32), dist_t.view(np.uint32))
+    assert not np.isnan(dist_f).any()                   # a NaN distance is THE positive quiet NaN in both forms and sorts last
+    # a NaN QUERY: every distance NaN, every key equal up to the index -> rows 0 .. k-1; the filtered form's lists overflow -> redone
+    q[3, 7] = np.nan
+    (ids_f, dist_f, st_f), (ids_t, dist_t, _) = _knn_both_forms(D, db, q, 100)
+    assert st_f["redone_unfiltered"] == 1
+    assert np.array_equal(ids_f[3], np.arange(100)) and np.isnan(dist_f[3]).all()
     assert np.array_equal(ids_f, ids_t) and np.array_equal(dist_f.view(np.uint32), dist_t.view(np.uint32))
 
 

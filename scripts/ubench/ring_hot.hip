@@ -2,10 +2,13 @@
 // per SIMD) when every wave feeds its chain from a REGISTER ring of plain global_load_dwordx4 over an L2-resident stream
 // (1 MiB, every workgroup walks the same one) -- the loop of the table kernels -- against MFMAs only.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 ring_hot.hip -o ring_hot && ./ring_hot
-// Result (profiles/r05g_ubench_ring_hot.log): ONE wave per SIMD 153 TFLOP/s with MFMAs only, 141-144 with the ring (depth 8 / 16):
-// the plain-load ring costs a single wave 7-9 %, hot.  The two-workgroups-per-CU rows are NOT understood and not used as evidence:
-// MFMAs only take exactly 3x the one-workgroup time for 2x the work (102.8 TFLOP/s) while every wave's own cycle counter shows the
-// full rate (256 cycles per fragment) -- as if a third of the workgroups ran alone after the others; with the ring 126-128 TFLOP/s.
+// Result (profiles/r05g_ubench_ring_hot.log; LDS padding pins the workgroups per CU, HW_ID confirms 1 or 2 waves on EVERY SIMD):
+//   one wave per SIMD:  MFMAs only 152 TFLOP/s (0.97), with the ring 142-145 (0.90-0.92): the plain-load ring costs a lone wave 7-9 %
+//   two waves per SIMD: MFMAs only 78-104 TFLOP/s (0.50-0.66, varies run to run; the measured wave of every workgroup still sees
+//                       256 cycles per fragment: the other wave of its SIMD starves, then runs), with the ring 126-129 (0.80-0.82)
+// i.e. two waves that both always have a dependent f32 MFMA ready do NOT share a SIMD's matrix pipe cleanly on this chip; every
+// two-workgroups-per-CU kernel of this library sits at or under that 0.80 (knn_table 0.77-0.80 in its loop, dist_topk_mfma 0.60,
+// the short-MLP instances 0.84), the one-wave-per-SIMD kernels at 0.92.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -16,7 +19,16 @@ constexpr int NF = 16;         // fragments per block (D = 128)
 constexpr int BLOCKS = 64;     // blocks per pass over the stream (1 MiB)
 
 template <int DEPTH, bool LOADS, int WPS>
-__global__ void __launch_bounds__(256) k(const f32x4* __restrict__ w, float* out, long long* cyc, int passes) {
+__global__ void __launch_bounds__(256) k(const f32x4* __restrict__ w, float* out, long long* cyc, int passes, long long* wall, unsigned long long* where) {
+  const long long w0 = wall_clock64();
+  if ((threadIdx.x & 63) == 0) {   // XCC id << 32 | HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SE/SH [15:12])
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    where[blockIdx.x * 4 + (threadIdx.x >> 6)] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+  }
+  __shared__ float pad[WPS == 2 ? 18 * 1024 : 36 * 1024];   // 72 / 144 KiB of LDS: exactly WPS workgroups fit a CU (without it the
+  pad[threadIdx.x] = 0.f;                                     // dispatcher put up to three of these small workgroups on one CU)
   const int lane = threadIdx.x & 63;
   const f32x4* wp = w + lane;
   f32x16 acc;
@@ -40,15 +52,17 @@ __global__ void __launch_bounds__(256) k(const f32x4* __restrict__ w, float* out
     }
   }
   long long t1 = __builtin_readcyclecounter();
-  float s = acc[0] + acc[9];
+  float s = acc[0] + acc[9] + pad[threadIdx.x];
   for (int i = 0; i < DEPTH; ++i) s += r[i][0];
   out[blockIdx.x * 256 + threadIdx.x] = s;
-  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+  if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; wall[2 * blockIdx.x] = w0; wall[2 * blockIdx.x + 1] = wall_clock64(); }
 }
 
 template <int DEPTH, bool LOADS, int WPS>
 void run(const f32x4* w, int passes) {
-  float* out; long long* cyc;
+  float* out; long long* cyc; long long* wall;
+  hipMalloc(&wall, 1024 * 16);
+  unsigned long long* where; hipMalloc(&where, 4096 * 8);
   const int grid = 256 * WPS;   // WPS workgroups of 4 waves per CU (a 512-thread workgroup does NOT spread its 8 waves 2 per SIMD:
                                 // MFMAs only took 3x the one-wave time, i.e. three waves on one SIMD)
   hipMalloc(&out, grid * 256 * 4); hipMalloc(&cyc, grid * 8);
@@ -56,7 +70,7 @@ void run(const f32x4* w, int passes) {
   float ms = 0.f;
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k<DEPTH, LOADS, WPS>), dim3(grid), dim3(256), 0, 0, w, out, cyc, passes);
+    hipLaunchKernelGGL((k<DEPTH, LOADS, WPS>), dim3(grid), dim3(256), 0, 0, w, out, cyc, passes, wall, where);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     hipEventElapsedTime(&ms, e0, e1);
@@ -66,7 +80,28 @@ void run(const f32x4* w, int passes) {
   double avg = 0; for (int i = 0; i < grid; ++i) avg += c[i]; avg /= grid;
   printf("ring depth %2d  loads %d  waves/SIMD %d: %.1f cycles per fragment per wave (ideal %d)  launch %.3f ms = %.1f TFLOP/s\n", DEPTH,
          (int)LOADS, WPS, avg / ((double)passes * BLOCKS * NF), 256 * WPS, ms, tflops);
-  hipFree(out); hipFree(cyc);
+  {  // when did the workgroups run?  (wall_clock64: 100 MHz)
+    static long long wl[2048]; hipMemcpy(wl, wall, grid * 16, hipMemcpyDeviceToHost);
+    long long lo = wl[0]; for (int i = 0; i < grid; ++i) lo = wl[2 * i] < lo ? wl[2 * i] : lo;
+    int late = 0; double life = 0, last = 0;
+    for (int i = 0; i < grid; ++i) {
+      const double st = (wl[2 * i] - lo) * 1e-5, en = (wl[2 * i + 1] - lo) * 1e-5;   // ms
+      late += st > 0.1; life += en - st; last = en > last ? en : last;
+    }
+    static unsigned long long wh[4096]; hipMemcpy(wh, where, grid * 4 * 8, hipMemcpyDeviceToHost);
+    int hist[9] = {0};   // SIMDs by the number of this launch's waves they hold
+    for (int i = 0; i < grid * 4; ++i) {
+      if (wh[i] == ~0ull) continue;
+      const unsigned long long key = ((wh[i] >> 32) << 16) | ((wh[i] >> 4) & 0xfff);
+      int n = 0;
+      for (int k = i; k < grid * 4; ++k)
+        if (wh[k] != ~0ull && ((((wh[k] >> 32) << 16) | ((wh[k] >> 4) & 0xfff)) == key)) { ++n; if (k != i) wh[k] = ~0ull; }
+      hist[n > 8 ? 8 : n]++;
+    }
+    printf("    SIMDs holding 1 / 2 / 3 / 4 / 5+ of the launch's waves: %d / %d / %d / %d / %d\n", hist[1], hist[2], hist[3], hist[4], hist[5] + hist[6] + hist[7] + hist[8]);
+    printf("    workgroups: %d of %d started more than 0.1 ms after the first; mean life %.3f ms; last end %.3f ms\n", late, grid, life / grid, last);
+  }
+  hipFree(out); hipFree(cyc); hipFree(wall);
 }
 int main() {
   const int passes = 32;

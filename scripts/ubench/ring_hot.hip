@@ -6,7 +6,9 @@
 //   one wave per SIMD:  MFMAs only 152 TFLOP/s (0.97), with the ring 142-145 (0.90-0.92): the plain-load ring costs a lone wave 7-9 %
 //   two waves per SIMD: MFMAs only 78-104 TFLOP/s (0.50-0.66, varies run to run; the measured wave of every workgroup still sees
 //                       256 cycles per fragment: the other wave of its SIMD starves, then runs), with the ring 126-129 (0.80-0.82)
-// i.e. two waves that both always have a dependent f32 MFMA ready do NOT share a SIMD's matrix pipe cleanly on this chip; every
+//   (cycles per fragment x fragments / launch time = 2.33 GHz with one wave, ~1.9 GHz with two + ring: part of the loss is the clock;
+//    s_setprio 3 / 0 by wave-slot parity: no change)
+// i.e. in delivered TFLOP/s two waves per SIMD that both always have a dependent f32 MFMA ready lose ~20 % against one; every
 // two-workgroups-per-CU kernel of this library sits at or under that 0.80 (knn_table 0.77-0.80 in its loop, dist_topk_mfma 0.60,
 // the short-MLP instances 0.84), the one-wave-per-SIMD kernels at 0.92.
 #include <hip/hip_runtime.h>
@@ -18,7 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NF = 16;         // fragments per block (D = 128)
 constexpr int BLOCKS = 64;     // blocks per pass over the stream (1 MiB)
 
-template <int DEPTH, bool LOADS, int WPS>
+template <int DEPTH, bool LOADS, int WPS, bool PRIO = false>
 __global__ void __launch_bounds__(256) k(const f32x4* __restrict__ w, float* out, long long* cyc, int passes, long long* wall, unsigned long long* where) {
   const long long w0 = wall_clock64();
   if ((threadIdx.x & 63) == 0) {   // XCC id << 32 | HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SE/SH [15:12])
@@ -26,6 +28,11 @@ __global__ void __launch_bounds__(256) k(const f32x4* __restrict__ w, float* out
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     where[blockIdx.x * 4 + (threadIdx.x >> 6)] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+  }
+  if (PRIO) {   // the two waves of a SIMD sit in different wave slots: the odd slot gets the higher priority
+    unsigned hw2;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw2));
+    if (hw2 & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
   }
   __shared__ float pad[WPS == 2 ? 18 * 1024 : 36 * 1024];   // 72 / 144 KiB of LDS: exactly WPS workgroups fit a CU (without it the
   pad[threadIdx.x] = 0.f;                                     // dispatcher put up to three of these small workgroups on one CU)
@@ -58,7 +65,7 @@ __global__ void __launch_bounds__(256) k(const f32x4* __restrict__ w, float* out
   if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; wall[2 * blockIdx.x] = w0; wall[2 * blockIdx.x + 1] = wall_clock64(); }
 }
 
-template <int DEPTH, bool LOADS, int WPS>
+template <int DEPTH, bool LOADS, int WPS, bool PRIO = false>
 void run(const f32x4* w, int passes) {
   float* out; long long* cyc; long long* wall;
   hipMalloc(&wall, 1024 * 16);
@@ -70,7 +77,7 @@ void run(const f32x4* w, int passes) {
   float ms = 0.f;
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k<DEPTH, LOADS, WPS>), dim3(grid), dim3(256), 0, 0, w, out, cyc, passes, wall, where);
+    hipLaunchKernelGGL((k<DEPTH, LOADS, WPS, PRIO>), dim3(grid), dim3(256), 0, 0, w, out, cyc, passes, wall, where);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     hipEventElapsedTime(&ms, e0, e1);
@@ -78,7 +85,7 @@ void run(const f32x4* w, int passes) {
   const double tflops = (double)grid * 4 * passes * BLOCKS * NF * 4 * 4096.0 / (ms * 1e-3) / 1e12;
   long long c[1024]; hipMemcpy(c, cyc, grid * 8, hipMemcpyDeviceToHost);
   double avg = 0; for (int i = 0; i < grid; ++i) avg += c[i]; avg /= grid;
-  printf("ring depth %2d  loads %d  waves/SIMD %d: %.1f cycles per fragment per wave (ideal %d)  launch %.3f ms = %.1f TFLOP/s\n", DEPTH,
+  printf("%sring depth %2d  loads %d  waves/SIMD %d: %.1f cycles per fragment per wave (ideal %d)  launch %.3f ms = %.1f TFLOP/s\n", PRIO ? "[prio by wave slot] " : "", DEPTH,
          (int)LOADS, WPS, avg / ((double)passes * BLOCKS * NF), 256 * WPS, ms, tflops);
   {  // when did the workgroups run?  (wall_clock64: 100 MHz)
     static long long wl[2048]; hipMemcpy(wl, wall, grid * 16, hipMemcpyDeviceToHost);
@@ -108,5 +115,6 @@ int main() {
   f32x4* w; size_t bytes = (size_t)(BLOCKS * NF + 64) * 1024; hipMalloc(&w, bytes); hipMemset(w, 0, bytes);
   run<8, false, 1>(w, passes); run<8, true, 1>(w, passes); run<16, true, 1>(w, passes);
   run<8, false, 2>(w, passes); run<8, true, 2>(w, passes); run<16, true, 2>(w, passes);
+  run<8, false, 2, true>(w, passes); run<8, true, 2, true>(w, passes); run<16, true, 2, true>(w, passes);
   return 0;
 }

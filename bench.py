@@ -549,6 +549,35 @@ def leg_decode_calls(torch, dev, eng, cfg, codes_all, rows, min_calls=8):
     return out
 
 
+def leg_small_db_search(torch, dev, N=1_000_000, Q=4096, D=128, k=100):
+    """f3 (run_search_full_direct_small_db, search_tasks.py:551-603) at bigann1M's shape: top-100 of 10^6 reconstructions for 4096
+    queries through the filtered form (no distance table in HBM; csrc/knn_kernel.hpp) and the table form; ids and distance bits must
+    be equal.  FLOPs = 2 D per pair (the distance table the reference computes with approx_pairwise_distance)."""
+    from qinco_amd.search import KnnSearcher
+    g = torch.Generator(device=dev).manual_seed(0)
+    db = torch.randn(N, D, device=dev, generator=g)
+    q = torch.randn(Q, D, device=dev, generator=g)
+    out = {"workload": f"top-{k} of {N} x {Q} queries, D={D}", "unit": "queries/s"}
+    got = {}
+    for name, filtered in (("filtered", True), ("table", False)):
+        knn = KnnSearcher(D, filtered=filtered)
+        knn.search(db, q, k=k)
+        torch.cuda.synchronize(dev)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            got[name] = knn.search(db, q, k=k, return_dist=True)
+            torch.cuda.synchronize(dev)
+            best = min(best, time.perf_counter() - t0)
+        out[name] = {"value": Q / best, "ms": best * 1e3, "tflops": 2.0 * D * N * Q / best / 1e12,
+                     "frac_fp32_mfma": 2.0 * D * N * Q / best / 1e12 / PEAK_FP32_MFMA_TFLOPS, **knn.last_stats()}
+        knn.close()
+    out["value"] = out["filtered"]["value"]
+    out["forms_equal_bit_for_bit"] = bool(torch.equal(got["filtered"][0], got["table"][0])
+                                          and torch.equal(got["filtered"][1].view(torch.int32), got["table"][1].view(torch.int32)))
+    return out
+
+
 def parity_counts(torch, dev):
     """Rows of the committed reference fixtures this build reproduces, on this GPU: tests/golden/<case>.npz holds the inputs and the
     codes / reconstructions the IMPORTED REFERENCE produced for them (tests/golden/make_golden.py ran /root/reference in the build
@@ -870,7 +899,8 @@ def main():
                             ("qinco2_S", lambda: leg_workload(torch, dev, "S", 6, 16384, decode_sizes=(1024, 12288, 16384))),
                             ("ivf_qinco2_S", lambda: leg_workload(torch, dev, "IVF_S", 6, 16384)),
                             ("encode_db_bvecs", lambda: leg_encode_db_bvecs(torch, dev, args.bvecs_vectors, 16384)),
-                            ("encode_db_bvecs_qinco2S", lambda: leg_encode_db_bvecs(torch, dev, args.bvecs_vectors, 16384, "S"))):
+                            ("encode_db_bvecs_qinco2S", lambda: leg_encode_db_bvecs(torch, dev, args.bvecs_vectors, 16384, "S")),
+                            ("small_db_search", lambda: leg_small_db_search(torch, dev))):
                 try:        # a leg can never take the headline down with it
                     out[key] = fn()
                 except Exception as e:                        # noqa: BLE001

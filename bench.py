@@ -145,6 +145,28 @@ def self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def rccl_world_of_one(timeout_s: float) -> dict:
+    """The N = 1 line's `rccl_world1`: `bench.py --gpus 1 --dry-rccl` in a child process (so that an RCCL that hangs or aborts
+    cannot take the bench line with it) -- a communicator of ONE rank on the real librccl: torch.distributed `nccl` group +
+    all_reduce + grouped isend / irecv to self + the product's gather_codes through its transfer lines, then ncclCommInitRank through
+    ctypes + qinco_gather_codes (grouped ncclSend / ncclRecv to self).  What a 1-GPU lease can execute of SURVEY 8(e)'s RCCL path."""
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--dry-rccl", "--dry-rows", "200000", "--no-affinity",
+           "--rccl-timeout", str(min(timeout_s, 120.0))]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=min(timeout_s, 120.0) * 3 + 120)
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        steps = rec["per_rank"][0]["steps"]
+        return {"all_ok": bool(rec["all_ok"]), "steps": {k: (True if v["ok"] else v.get("error")) for k, v in steps.items()},
+                "rccl_ranks_seen": rec.get("rccl_ranks_seen"), "nccl_comm_count": rec.get("nccl_comm_count"),
+                "rccl_library": rec.get("rccl_library"), "torch_nccl_version": rec.get("torch_nccl_version"),
+                "seconds": time.perf_counter() - t0, "command": "bench.py --gpus 1 --dry-rccl (child process, untimed)"}
+    except Exception as e:                                    # noqa: BLE001 -- never the headline's problem
+        return {"all_ok": False, "error": f"{type(e).__name__}: {e}"[:300], "seconds": time.perf_counter() - t0}
+
+
 def call_with_timeout(fn, seconds):
     """Run fn() on a helper thread; TimeoutError if it has not returned after `seconds` (a wedged RCCL call must not take
     the whole run with it: the caller falls back to part files and the process leaves through os._exit at the end)."""
@@ -231,30 +253,29 @@ def dry_rccl(torch, dist, args, rank, world, dev, dev_index, data_group, data_no
             torch.cuda.set_device(dev_index)
 
     def p2p():
-        if world == 1:
-            return {"peers": 0}
         set_device()
-        send = torch.full((1,), rank, dtype=torch.uint8, device=pdev)
+        send = torch.full((1,), rank + 7 * (world == 1), dtype=torch.uint8, device=pdev)
         recv = [torch.full((1,), 255, dtype=torch.uint8, device=pdev) for _ in range(world)]
+        peers = [p for p in range(world) if p != rank] or [rank]      # (a world of one: the grouped send / recv with ITSELF)
         ops = []
-        for peer in range(world):
-            if peer != rank:
-                ops.append(dist.P2POp(dist.isend, send, peer, group=data_group))
-                ops.append(dist.P2POp(dist.irecv, recv[peer], peer, group=data_group))
+        for peer in peers:
+            ops.append(dist.P2POp(dist.isend, send, peer, group=data_group))
+            ops.append(dist.P2POp(dist.irecv, recv[peer], peer, group=data_group))
         for q in dist.batch_isend_irecv(ops):
             q.wait()
         if use_rccl:
             torch.cuda.synchronize(dev)
-        got = [int(recv[p].item()) for p in range(world) if p != rank]
-        if got != [p for p in range(world) if p != rank]:
+        got = [int(recv[p].item()) for p in peers]
+        if got != ([7] if world == 1 else peers):
             raise RuntimeError(f"wrong bytes from the peers: {got}")
-        return {"peers": len(got)}
+        return {"peers": len(got), "self": world == 1}
 
     gst: dict = {}
 
     def gather():
         set_device()
-        full = gather_codes(mine_np, N, dist, device=dev if use_rccl else None, code_dtype="compact", group=data_group, stats=gst)
+        full = gather_codes(mine_np, N, dist, device=dev if use_rccl else None, code_dtype="compact", group=data_group, stats=gst,
+                            self_transfer=world == 1)
         if rank == 0:
             if full.shape != (N, M) or not np.array_equal(full, fake_code_rows(0, N, M)):
                 raise RuntimeError("the gathered matrix is not the database's codes")
@@ -270,12 +291,16 @@ def dry_rccl(torch, dist, args, rank, world, dev, dev_index, data_group, data_no
         ok = True
         if rank == 0:
             ok = bool(np.array_equal(out.cpu().numpy(), fake_code_rows(0, N, M)))
+        lib_path = comm.library_path()                        # (dladdr of the ncclSend qinco_gather_codes called)
+        made_by = os.path.realpath(comm.rccl._name)
         comm.close()
         if not ok:
             raise RuntimeError("qinco_gather_codes: the gathered matrix is not the database's codes")
-        return {"nccl_comm_count": seen}
+        if os.path.realpath(lib_path) != made_by:
+            raise RuntimeError(f"qinco_gather_codes called {lib_path} but the communicator was made by {made_by}")
+        return {"nccl_comm_count": seen, "rccl_library": lib_path}
 
-    if world > 1 and (use_rccl or args.backend == "gloo"):
+    if (world > 1 and (use_rccl or args.backend == "gloo")) or (world == 1 and use_rccl):
         step("p2p_1_byte_with_every_peer", p2p)
         step("gather_codes", gather)
         if use_rccl:
@@ -294,6 +319,8 @@ def dry_rccl(torch, dist, args, rank, world, dev, dev_index, data_group, data_no
                "steps_ok_on_all_ranks": {k: all(r["steps"].get(k, {}).get("ok", False) for r in allr) for k in names},
                "rccl_ranks_seen": steps.get("gather_codes", {}).get("ranks"),
                "nccl_comm_count": steps.get("native_qinco_gather_codes", {}).get("nccl_comm_count"),
+               "rccl_library": steps.get("native_qinco_gather_codes", {}).get("rccl_library"),
+               "torch_nccl_version": list(torch.cuda.nccl.version()) if use_rccl else None,
                "per_rank": allr}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -302,7 +329,7 @@ def dry_rccl(torch, dist, args, rank, world, dev, dev_index, data_group, data_no
     if wedged:
         sys.stderr.flush()
         os._exit(0)
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
     return 0
 
@@ -641,6 +668,7 @@ def main():
                     help="no model, no encode: build the communicator(s), one 1-byte grouped send / recv with every peer, then the product's "
                          "gather_codes (and the C-ABI qinco_gather_codes) on --dry-rows fake code rows, each step under --rccl-timeout; "
                          "prints one JSON line saying which steps worked on which rank (first contact with a multi-GPU node in seconds)")
+    ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: skip the world-of-one RCCL check (`rccl_world1` on the line)")
     ap.add_argument("--dry-rows", type=int, default=1_000_000, help="--dry-rccl: rows of the fake database")
     ap.add_argument("--c1-cpu-vectors", type=int, default=256,
                     help="vectors of the c1 leg's CPU sample (BASELINE.md 3 / SURVEY 8d quote C1's CPU protocol at 10 000: minutes of host time)")
@@ -682,9 +710,14 @@ def main():
     # control plane on gloo (always works on one node), payload on RCCL when asked for and available
     data_group, data_note = None, None
     wedged = False            # an RCCL call timed out: its thread is still stuck, so the process must leave through os._exit
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if world > 1 or args.dry_rccl:
+        # (--dry-rccl at --gpus 1: a job of ONE rank still builds both groups -- gloo control plane, RCCL payload group -- so that
+        # a 1-GPU box executes every communication line of the multi-GPU bench on the real library, rank 0 in both roles)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{_free_port()}")
         if args.backend == "nccl":
             ok = 1
             try:
@@ -696,12 +729,13 @@ def main():
                     dist.all_reduce(probe, group=data_group)
                     # ... and the gather's own point-to-point pattern once with one byte per rank: whatever the backend builds lazily
                     # for a (rank, 0) pair is built here, not inside the timed region
-                    if rank == 0:
-                        box = torch.zeros(world, dtype=torch.uint8, device=dev)
-                        for q in [dist.irecv(box[r:r + 1], src=r, group=data_group) for r in range(1, world)]:
-                            q.wait()
-                    else:
-                        dist.send(torch.full((1,), rank, dtype=torch.uint8, device=dev), dst=0, group=data_group)
+                    # (one batch per rank, as gather_codes issues them; a world of one talks to itself)
+                    box = torch.zeros(world, dtype=torch.uint8, device=dev)
+                    ops = [dist.P2POp(dist.irecv, box[r:r + 1], r, group=data_group) for r in range(1 if world > 1 else 0, world)] if rank == 0 else []
+                    if rank != 0 or world == 1:
+                        ops.append(dist.P2POp(dist.isend, torch.full((1,), rank, dtype=torch.uint8, device=dev), 0, group=data_group))
+                    for q in dist.batch_isend_irecv(ops):
+                        q.wait()
                     torch.cuda.synchronize(dev)
                 call_with_timeout(probe_rccl, args.rccl_timeout)
             except BaseException as e:                        # noqa: BLE001 -- any failure or a hang: part files instead
@@ -889,6 +923,9 @@ def main():
                 "per_rank": per_rank,
                 "note": "gather time of a rank includes waiting for the slowest rank's encode",
             }
+        if world == 1 and not args.no_rccl_check:
+            out["rccl_world1"] = rccl_world_of_one(args.rccl_timeout)
+            out["rccl_world1_ok"] = bool(out["rccl_world1"].get("all_ok", False))
         if world == 1 and not args.no_extras and K > 0 and not strong and not cfg.ivf:
             extras(torch, dev, args, cfg, sd, eng, out, mine, batches, warm, value, sqerr_sum, QincoEngine)
         if world == 1 and not args.no_legs and not args.split_f16:

@@ -21,6 +21,7 @@
 #define QINCO_HIP_H
 
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -222,11 +223,17 @@ QINCO_API int qinco_load_instance(const char* path);
  * communicator: grouped ncclSend / ncclRecv of the raw code bytes (each peer reaches the root over its own xGMI link).
  *   codes_local  device (n_local, M) of code_dtype on this rank          counts[world]  rows of every rank (shards are uneven:
  *   out          device (sum counts, M) on `root` (ignored elsewhere)                   the last one takes the remainder)
- *   nccl_comm    the host's ncclComm_t (one rank per GPU); world == 1 needs none: a device copy
+ *   nccl_comm    the host's ncclComm_t (one rank per GPU); world == 1 needs none: a device copy.  A communicator of ONE rank,
+ *                when given, is used: the shard goes through a grouped ncclSend-to-self + ncclRecv-from-self (the many-rank
+ *                sequence on the real library -- what a 1-GPU box can execute of it)
  * Enqueued on `stream`, not synchronised.  RCCL is resolved at call time from the libraries already loaded in the process
  * (the one that made the communicator), else librccl.so.1; QINCO_ERR_UNSUPPORTED when there is none. */
 QINCO_API int qinco_gather_codes(const void* codes_local, int64_t n_local, int32_t M, int code_dtype, void* out,
                                  const int64_t* counts, int32_t world, int32_t rank, int32_t root, void* nccl_comm, void* stream);
+/* The shared object qinco_gather_codes' ncclSend resolved to (dladdr; at most cap bytes with the terminator): a PyTorch process
+ * holds the wheel's own librccl.so next to /opt/rocm's, and a communicator works only with the library that created it.
+ * (No reference counterpart: torch.distributed hides the choice, qinco/search/search_tasks.py:85-137 runs under accelerate.) */
+QINCO_API int qinco_rccl_library(char* path, size_t cap);
 
 /* ---- look-up decoders downstream of the hot path --------------------------------------------
  * out[n] = sum_j tables[j][ codes[n][a[j]] * mul + (b[j] >= 0 ? codes[n][b[j]] : 0) ]   (fp32, summed in j order)

@@ -17,7 +17,7 @@ CREATE_NO_EPILOGUE_SELECT = 512
 
 # every symbol include/qinco_hip.h declares (tests check the library exports all of them)
 API_SYMBOLS = [
-    "qinco_create", "qinco_create_ex", "qinco_create_opt", "qinco_describe", "qinco_padded_shape", "qinco_load_instance", "qinco_split_stats", "qinco_gather_codes", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
+    "qinco_create", "qinco_create_ex", "qinco_create_opt", "qinco_describe", "qinco_padded_shape", "qinco_load_instance", "qinco_split_stats", "qinco_gather_codes", "qinco_rccl_library", "qinco_destroy", "qinco_set_beam", "qinco_encode", "qinco_decode", "qinco_encode_host",
     "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_profile_read2", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
     "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
@@ -108,6 +108,8 @@ def load() -> C.CDLL:
     lib.qinco_load_instance.restype = C.c_int
     lib.qinco_gather_codes.argtypes = [vp, i64, C.c_int32, i32, vp, C.POINTER(i64), C.c_int32, C.c_int32, C.c_int32, vp, vp]
     lib.qinco_gather_codes.restype = C.c_int
+    lib.qinco_rccl_library.argtypes = [C.c_char_p, C.c_size_t]
+    lib.qinco_rccl_library.restype = C.c_int
     lib.qinco_split_stats.argtypes = [vp, C.POINTER(QincoSplitReport)]
     lib.qinco_split_stats.restype = C.c_int
     lib.qinco_describe.argtypes = [vp, C.c_char_p, C.c_int32]

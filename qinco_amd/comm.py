@@ -47,13 +47,15 @@ class RcclComm:
     * `id_file` + `nonce` -- rank 0 writes `id || nonce` and the others accept only a file that ends in THEIR nonce (a job id, the
       launcher's run id, a random token passed on the command line): a file left behind by an earlier job under the same path can
       never be taken for this job's, however late a rank starts and whatever the clocks of the hosts / the file server say;
-    * `id_file` alone -- single-host fall-back: a file is fresh when it was written at most `timeout_s` before this rank started,
-      measured on this host's clock (the skew a late rank is allowed equals the time rank 0 is prepared to wait for it).
+    * `id_file` alone -- single-host fall-back: a file is fresh when it was written at most `max_skew_s` (30 s) before this rank
+      started, measured on this host's clock -- short on purpose: a file left by a job that died a minute ago under the same path
+      must not be taken for this job's (the ranks would block in ncclCommInitRank on a dead id).  Launchers whose ranks start
+      further apart pass a nonce.
 
     Rank 0 replaces the file atomically and removes it once every rank has joined (ncclCommInitRank is collective)."""
 
     def __init__(self, rank: int, world: int, id_file: Optional[str] = None, timeout_s: float = 120.0, nonce: Optional[str] = None,
-                 uid: Optional[bytes] = None):
+                 uid: Optional[bytes] = None, max_skew_s: float = 30.0):
         _lib.load()                      # one HIP runtime first
         self.rccl = _librccl()
         self.rank, self.world = rank, world
@@ -65,7 +67,7 @@ class RcclComm:
             uid_s = NcclUniqueId()
             C.memmove(C.byref(uid_s), bytes(uid), 128)
         else:
-            uid_s = self._exchange_through_file(rank, id_file, timeout_s, nonce)
+            uid_s = self._exchange_through_file(rank, id_file, timeout_s, nonce, max_skew_s)
         self.comm = C.c_void_p()
         self.rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
         self._ok(self.rccl.ncclCommInitRank(C.byref(self.comm), world, uid_s, rank))
@@ -95,6 +97,21 @@ class RcclComm:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         return cls(rank, world, uid=box[0])
 
+    @classmethod
+    def world_of_one(cls) -> "RcclComm":
+        """A communicator with this process as its only rank (ncclGetUniqueId -> ncclCommInitRank(nranks = 1)): what a 1-GPU
+        box can create on the real library; qinco_gather_codes routes its shard through it (send-to-self + recv-from-self)."""
+        probe = cls.__new__(cls)
+        _lib.load()
+        probe.rccl = _librccl()
+        return cls(0, 1, uid=probe.new_unique_id())
+
+    def library_path(self) -> str:
+        """The shared object whose ncclSend / ncclRecv qinco_gather_codes calls in this process (dladdr, qinco_rccl_library)."""
+        buf = C.create_string_buffer(4096)
+        _lib.check(_lib.load().qinco_rccl_library(buf, len(buf)))
+        return buf.value.decode()
+
     def count(self) -> int:
         """ncclCommCount: the ranks RCCL itself sees in this communicator."""
         n = C.c_int(0)
@@ -102,7 +119,8 @@ class RcclComm:
         self._ok(self.rccl.ncclCommCount(self.comm, C.byref(n)))
         return n.value
 
-    def _exchange_through_file(self, rank: int, id_file: str, timeout_s: float, nonce: Optional[str]) -> NcclUniqueId:
+    def _exchange_through_file(self, rank: int, id_file: str, timeout_s: float, nonce: Optional[str],
+                               max_skew_s: float = 30.0) -> NcclUniqueId:
         uid = NcclUniqueId()
         tag = nonce.encode() if nonce is not None else b""
         born = time.time()
@@ -120,7 +138,7 @@ class RcclComm:
                 if nonce is not None:
                     ok = len(blob) == 128 + len(tag) and blob[128:] == tag       # this job's file: no clock is consulted
                 else:
-                    ok = len(blob) == 128 and os.path.getmtime(id_file) >= born - timeout_s
+                    ok = len(blob) == 128 and os.path.getmtime(id_file) >= born - max_skew_s
             except OSError:
                 ok = False
             if ok:

@@ -68,14 +68,35 @@ extern "C" int qinco_gather_codes(const void* codes_local, int64_t n_local, int3
   const size_t rowb = (size_t)M * esz;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n_local > 0 && !codes_local) return fail(QINCO_ERR_INVALID, "qinco_gather_codes: null codes_local");
-  if (rank == root && !out) return fail(QINCO_ERR_INVALID, "qinco_gather_codes: the root needs an output buffer");
-  if (world == 1) {
+  int64_t total = 0;
+  for (int r = 0; r < world; ++r) {
+    if (counts[r] < 0) return fail(QINCO_ERR_INVALID, "qinco_gather_codes: counts[%d] = %ld", r, (long)counts[r]);
+    total += counts[r];
+  }
+  if (rank == root && !out && total > 0) return fail(QINCO_ERR_INVALID, "qinco_gather_codes: the root needs an output buffer");
+  if (world == 1 && !nccl_comm) {   // a job of one rank without a communicator: a device copy
     if (n_local > 0) HIP_TRY(hipMemcpyAsync(out, codes_local, (size_t)n_local * rowb, hipMemcpyDeviceToDevice, st));
     return QINCO_OK;
   }
   if (!nccl_comm) return fail(QINCO_ERR_INVALID, "qinco_gather_codes: null communicator");
   const Rccl& R = rccl();
   if (!R.ok()) return fail(QINCO_ERR_UNSUPPORTED, "qinco_gather_codes: no RCCL in this process (ncclSend / ncclRecv not found; librccl.so.1 not loadable)");
+  if (world == 1) {
+    // A communicator of ONE rank was handed in: the shard still travels through RCCL -- one grouped ncclSend to self +
+    // ncclRecv from self, the same group / send / recv / stream sequence as the many-rank path below.  This is what a 1-GPU
+    // box can execute of that path on the real library (tests/test_multi_gpu.py::test_rccl_world_of_one).
+    if (n_local > 0) {
+      RCCL_TRY(R.group_start());
+      int grc = R.send(const_cast<void*>(codes_local), (size_t)n_local * rowb, kNcclUint8, 0, nccl_comm, st);
+      if (grc == 0) grc = R.recv(out, (size_t)n_local * rowb, kNcclUint8, 0, nccl_comm, st);
+      if (grc != 0) {
+        (void)R.group_end();
+        RCCL_TRY(grc);
+      }
+      RCCL_TRY(R.group_end());
+    }
+    return QINCO_OK;
+  }
   RCCL_TRY(R.group_start());
   // (an error inside the group must still CLOSE it -- an open group on this thread would swallow every later collective of the process)
   int grc = 0;
@@ -99,5 +120,19 @@ extern "C" int qinco_gather_codes(const void* codes_local, int64_t n_local, int3
     for (int r = 0; r < root; ++r) off += (size_t)counts[r] * rowb;
     HIP_TRY(hipMemcpyAsync(static_cast<char*>(out) + off, codes_local, (size_t)n_local * rowb, hipMemcpyDeviceToDevice, st));
   }
+  return QINCO_OK;
+}
+
+// Which RCCL this process's qinco_gather_codes calls: the path of the shared object that ncclSend resolved to (dladdr) --
+// PyTorch wheels carry their own librccl.so next to /opt/rocm's, and a communicator must be used with the library that made it.
+extern "C" int qinco_rccl_library(char* path, size_t cap) {
+  if (!path || cap == 0) return fail(QINCO_ERR_INVALID, "qinco_rccl_library: null buffer");
+  const Rccl& R = rccl();
+  if (!R.ok()) return fail(QINCO_ERR_UNSUPPORTED, "qinco_rccl_library: no RCCL in this process (ncclSend / ncclRecv not found; librccl.so.1 not loadable)");
+  Dl_info info;
+  if (!dladdr(reinterpret_cast<void*>(R.send), &info) || !info.dli_fname) return fail(QINCO_ERR_UNSUPPORTED, "qinco_rccl_library: dladdr could not place ncclSend");
+  size_t n = 0;
+  while (info.dli_fname[n] && n + 1 < cap) { path[n] = info.dli_fname[n]; ++n; }
+  path[n] = 0;
   return QINCO_OK;
 }

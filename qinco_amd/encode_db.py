@@ -456,7 +456,7 @@ def _load_part(path: str, rows: int, cols=None, header_ok: bool = True) -> Optio
 
 
 def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None, code_dtype=np.int64, group=None,
-                 stats: Optional[dict] = None) -> Optional[np.ndarray]:
+                 stats: Optional[dict] = None, self_transfer: bool = False) -> Optional[np.ndarray]:
     """The per-rank code shards to rank 0: every rank sends its shard once, rank 0 receives each one straight into
     its rows of ONE preallocated (N, M) matrix of the wire type -- uint8 when every code is below 256 (M bytes per vector), else
     the shards' own type -- so the collective costs rank 0 one copy of the payload (8 GB at 10^9 x 8 codes), not a padded bucket
@@ -466,13 +466,20 @@ def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None, code_
 
     group: the process group that carries the payload (default: the default group) -- a job whose default group is a gloo control
     plane passes its "nccl" sub-group here and the transfers run on RCCL from device buffers.  Call sequence on RCCL, per rank:
-    all_reduce(MAX) of one int32 (the wire type), then rank r > 0: ONE send of its (n_r, M) shard; rank 0: world - 1 irecv, each
-    into its row range of the (N, M) matrix, wait, one D2H copy.  stats (optional dict) receives wire_dtype, bytes_sent,
-    bytes_received, ranks (the group's size as torch.distributed sees it) and the seconds spent in the transfers."""
+    all_reduce(MAX) of one int32 (the wire type), then ONE batch_isend_irecv (ncclGroupStart ... ncclGroupEnd) -- rank r > 0: one
+    isend of its (n_r, M) shard; rank 0: world - 1 irecv, each into its row range of the (N, M) matrix -- wait, and on rank 0 one
+    D2H copy.  stats (optional dict) receives wire_dtype, bytes_sent, bytes_received, ranks (the group's size as torch.distributed
+    sees it) and the seconds spent in the transfers.
+
+    self_transfer: a job of ONE rank normally has nothing to move and returns its shard.  With self_transfer=True (and an
+    initialised process group) it runs the very same lines with rank 0 in both roles -- the all_reduce, then one grouped isend to
+    itself + irecv from itself -- which is how a 1-GPU box executes this function on the real RCCL
+    (tests/test_multi_gpu.py::test_torch_rccl_world_of_one, bench.py --gpus 1 --dry-rccl)."""
     import time
     rank, world = _dist_info(dist)
     compact = isinstance(code_dtype, str) and code_dtype == "compact"
-    if world == 1:
+    loopback = world == 1 and self_transfer and dist is not None and dist.is_available() and dist.is_initialized()
+    if world == 1 and not loopback:
         return codes_local if compact else codes_local.astype(code_dtype, copy=False)
     import torch
     if group is not None and dist.get_world_size(group) != world:
@@ -491,27 +498,32 @@ def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None, code_
     if stats is not None:
         stats.update(wire_dtype=np.dtype(wire).name, ranks=int(dist.get_world_size(group)), bytes_sent=0, bytes_received=0,
                      transport=str(dist.get_backend(group)), buffers="device" if device is not None else "host")
-    if rank != 0:
-        if len(mine):
-            dist.send(mine, dst=0, group=group)
-            if device is not None:
-                torch.cuda.synchronize(device)       # (RCCL's send returns when it is enqueued: the seconds below are the transfer's)
-        if stats is not None:
-            stats.update(bytes_sent=int(mine.numel() * mine.element_size()), seconds=time.perf_counter() - t0)
-        return codes_local
-    full = torch.empty((db_size, M), dtype=mine.dtype, device=mine.device)
-    s0, e0 = shard_bounds(db_size, world, 0)
-    full[s0:e0] = mine
-    reqs = []
-    for r in range(1, world):
-        s, e = shard_bounds(db_size, world, r)
-        if e > s:
-            reqs.append(dist.irecv(full[s:e], src=r, group=group))
-    for q in reqs:
-        q.wait()
-    out = full.cpu().numpy()
+    # this rank's transfers, issued as ONE batch (RCCL: one ncclGroupStart / ncclGroupEnd; gloo: the ops one by one)
+    ops, full, received = [], None, 0
+    sender = rank != 0 or loopback
+    if sender and len(mine):
+        ops.append(dist.P2POp(dist.isend, mine, 0, group=group))
+    if rank == 0:
+        full = torch.empty((db_size, M), dtype=mine.dtype, device=mine.device)
+        if not loopback:                             # rank 0's own shard: a copy into its rows
+            s0, e0 = shard_bounds(db_size, world, 0)
+            full[s0:e0] = mine
+        for r in range(0 if loopback else 1, world):
+            s, e = shard_bounds(db_size, world, r)
+            if e > s:
+                ops.append(dist.P2POp(dist.irecv, full[s:e], r, group=group))
+                received += (e - s) * M * mine.element_size()
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+    if device is not None and ops:
+        torch.cuda.synchronize(device)               # (RCCL's calls return when they are enqueued: the seconds below are the transfer's)
     if stats is not None:
-        stats.update(bytes_received=int((db_size - (e0 - s0)) * M * mine.element_size()), seconds=time.perf_counter() - t0)
+        stats.update(bytes_sent=int(mine.numel() * mine.element_size()) if sender else 0, bytes_received=int(received),
+                     seconds=time.perf_counter() - t0)
+    if rank != 0:
+        return codes_local
+    out = full.cpu().numpy()
     return out if compact else out.astype(code_dtype, copy=False)
 
 

@@ -371,7 +371,7 @@ def test_rccl_id_file_is_matched_by_nonce_not_by_clock(tmp_path):
     """RcclComm's id exchange (qinco_amd/comm.py), the waiting ranks' side -- no RCCL call is made here.  With a job nonce a file is
     this job's iff it ends in the nonce: a day-old file with the right nonce is taken (a rank may start arbitrarily late, clocks
     may disagree), a brand-new file of another job is not.  Without a nonce the single-host rule applies: not older than
-    timeout_s before this rank's start."""
+    max_skew_s (30 s) before this rank's start, whatever timeout_s the rank is prepared to wait."""
     import time
     from qinco_amd.comm import RcclComm
     c = RcclComm.__new__(RcclComm)
@@ -384,8 +384,13 @@ def test_rccl_id_file_is_matched_by_nonce_not_by_clock(tmp_path):
     assert bytes(uid.internal) == blob
     with pytest.raises(TimeoutError, match="job-42"):
         c._exchange_through_file(1, f, 0.3, "job-42")                       # another job's file, however fresh
-    open(f, "wb").write(blob)                                               # no nonce: the mtime rule, with timeout_s of slack
+    open(f, "wb").write(blob)                                               # no nonce: the mtime rule, max_skew_s of slack
     assert bytes(c._exchange_through_file(2, f, 5.0, None).internal) == blob
+    minute_old = time.time() - 60                                           # a job that died a minute ago left it: not ours,
+    os.utime(f, (minute_old, minute_old))                                   # although this rank would wait 120 s for rank 0
+    with pytest.raises(TimeoutError):
+        c._exchange_through_file(2, f, 0.3, None)
+    assert bytes(c._exchange_through_file(2, f, 0.3, None, max_skew_s=90.0).internal) == blob
     os.utime(f, (old, old))
     with pytest.raises(TimeoutError):
         c._exchange_through_file(2, f, 0.3, None)

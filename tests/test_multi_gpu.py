@@ -161,6 +161,75 @@ def test_bench_strong_scaling_splits_one_database():
     assert abs(rec["value"] - 1636 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-6
 
 
+def test_rccl_world_of_one():
+    """First contact with the real librccl on a 1-GPU box (search_tasks.py:85-137, run.sh:8): a communicator of ONE rank
+    made through ctypes, ncclCommCount == 1, and qinco_gather_codes routing every code type -- odd byte counts, an empty shard --
+    through a grouped ncclSend-to-self + ncclRecv-from-self ON that communicator; the library whose ncclSend the C ABI resolved
+    (dladdr) is the one that made the communicator."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "rccl_world1_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])     # (RCCL prints its banner on stdout too)
+    print("RCCL resolved by qinco_gather_codes:", rec["library"])
+    assert rec["count"] == 1
+    assert os.path.realpath(rec["library"]) == rec["made_by"] and "rccl" in os.path.basename(rec["library"])
+    assert len(rec["cases"]) == 12 and all(c["equal"] for c in rec["cases"]), rec["cases"]
+    assert rec["copy_route_equal"]
+
+
+def test_torch_rccl_world_of_one():
+    """`bench.py --gpus 1 --dry-rccl`: torch.distributed with a gloo control plane and an `nccl` (= RCCL) payload group of ONE rank:
+    all_reduce, a grouped isend / irecv with itself (batch_isend_irecv), the product's gather_codes run through its transfer lines on
+    device buffers (self_transfer: rank 0 in both roles; encode_db.gather_codes), then the C-ABI route (RcclComm.from_process_group
+    -> qinco_gather_codes).  Every step on the real library."""
+    rec = _bench("--gpus", "1", "--dry-rccl", "--rccl-timeout", "120", "--dry-rows", "300001")
+    assert rec["n_gpus"] == 1 and rec["all_ok"], rec
+    want = {"communicator", "p2p_1_byte_with_every_peer", "gather_codes", "native_qinco_gather_codes"}
+    assert set(rec["steps_ok_on_all_ranks"]) == want and all(rec["steps_ok_on_all_ranks"].values()), rec
+    st = rec["per_rank"][0]["steps"]
+    assert st["communicator"]["backend"] == "rccl" and st["communicator"]["ranks"] == 1
+    assert st["p2p_1_byte_with_every_peer"]["self"] is True
+    g = st["gather_codes"]
+    assert g["transport"] == "nccl" and g["buffers"] == "device" and g["wire_dtype"] == "uint8"
+    assert g["bytes_sent"] == g["bytes_received"] == 300001 * 8                # (the whole shard went out and came back)
+    assert rec["nccl_comm_count"] == 1 and "rccl" in os.path.basename(rec["rccl_library"])
+    print("RCCL:", rec["rccl_library"], rec["torch_nccl_version"])
+
+
+def test_gather_codes_self_transfer_on_rccl_every_wire_type():
+    """encode_db.gather_codes on an `nccl` group of one rank with self_transfer: the three wire types (bytes; int32 with an IVF
+    column; int64) and an empty shard, each through all_reduce + one grouped isend / irecv on device buffers."""
+    code = r"""
+import json, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from qinco_amd.encode_db import gather_codes
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:" + sys.argv[2])
+g = dist.new_group(backend="nccl", device_id=torch.device("cuda", 0))
+rng = np.random.default_rng(3)
+out = []
+for hi, dt, wire in ((256, np.int64, "uint8"), (2 ** 20, np.int32, "int32"), (2 ** 40, np.int64, "int64")):
+    for n in (1, 4099, 0):
+        a = rng.integers(0, hi, size=(n, 9)).astype(dt)
+        if n: a[0, 0] = hi - 1
+        st = {}
+        got = gather_codes(a, n, dist, device=torch.device("cuda", 0), group=g, stats=st, self_transfer=True)
+        out.append({"equal": bool(np.array_equal(got, a.astype(np.int64))) and got.dtype == np.int64, "wire": st["wire_dtype"],
+                    "want_wire": wire if n else "uint8", "sent": st["bytes_sent"], "recv": st["bytes_received"], "n": n})
+print(json.dumps(out))
+dist.destroy_process_group()
+"""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code, str(ROOT), str(_free_port())], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("[{")][-1])
+    assert len(out) == 9
+    for c in out:
+        assert c["equal"] and c["wire"] == c["want_wire"] and c["sent"] == c["recv"], c
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_dry_rccl_on_the_gpu_box(world):
     """`bench.py --gpus N --dry-rccl`: the communication steps of the multi-GPU bench alone (payload group, a grouped 1-byte send /

@@ -94,6 +94,55 @@ def pmc_traffic_per_row():
     return None, None
 
 
+def pmc_traffic_live(args, kernel_substr: str = "mlp_kernel<") -> dict:
+    """`roofline.traffic` measured for THIS run's command: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one
+    pass -- MI355X_MICROARCH.md, PMC slots) of `bench.py --steps 2 --warmup 1` with this run's workload and batch, as child
+    processes (counters cannot be read from inside the timed process), untimed.  Per pass: the dispatches of the dominant kernel
+    at its largest grid (the full-size launches of the timed loop), mean counter value and mean duration.  FETCH_SIZE / WRITE_SIZE
+    are KiB; FETCH_SIZE counts half of the bytes of wide coalesced reads on gfx950 (same guide): x2.  Returns {"ok": False, "error"}
+    when rocprofv3 is not there or a pass fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {"ok": False, "error": "rocprofv3 not found"}
+    child = [sys.executable, str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--workload", args.workload, "--batch", str(args.batch),
+             "--no-cpu-baseline", "--no-extras", "--no-legs", "--no-rccl-check", "--no-pmc", "--no-affinity"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    out = {"ok": True, "passes": {}}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="qinco_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "t", "--", *child], cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=240)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return {"ok": False, "error": f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(dbs)} db; {r.stderr[-200:]}"}
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute("select kernel_name, grid_size, value, duration from counters_collection where counter_name = ? and "
+                               "kernel_name like ?", (counter, f"%{kernel_substr}%")).fetchall()
+            if not rows:
+                return {"ok": False, "error": f"no {kernel_substr} dispatch with {counter} in the pass"}
+            gmax = max(g for _, g, _, _ in rows)
+            full = [(v, du, k) for k, g, v, du in rows if g == gmax]
+            out["passes"][counter] = {"kernel": full[0][2][:80], "dispatches": len(full), "grid_threads": int(gmax),
+                                      "mean_kib": sum(v for v, _, _ in full) / len(full),
+                                      "mean_duration_us": sum(du for _, du, _ in full) / len(full) / 1e3}
+        except Exception as e:                                # noqa: BLE001 -- never the headline's problem
+            return {"ok": False, "error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    f, w = out["passes"]["FETCH_SIZE"], out["passes"]["WRITE_SIZE"]
+    out["fetch_bytes_x2"] = f["mean_kib"] * 1024 * 2
+    out["write_bytes"] = w["mean_kib"] * 1024
+    out["bytes_per_launch"] = out["fetch_bytes_x2"] + out["write_bytes"]
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
 def cpu_threads(torch) -> int:
     # The reference's own CPU protocol runs 32 ATen threads (qinco_tasks.py:492).  On this box (128 cores) more threads are
     # slower: 16 / 32 / 64 / 128 threads gave 39 / 41 / 33 / 20 vectors/s at batch 1024 (profiles/r02_cpu_sweep.jsonl).
@@ -668,6 +717,8 @@ def main():
                     help="no model, no encode: build the communicator(s), one 1-byte grouped send / recv with every peer, then the product's "
                          "gather_codes (and the C-ABI qinco_gather_codes) on --dry-rows fake code rows, each step under --rccl-timeout; "
                          "prints one JSON line saying which steps worked on which rank (first contact with a multi-GPU node in seconds)")
+    ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic with rocprofv3 --pmc child passes (it then "
+                                                          "falls back to the committed pass's bytes per row, and says so)")
     ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: skip the world-of-one RCCL check (`rccl_world1` on the line)")
     ap.add_argument("--dry-rows", type=int, default=1_000_000, help="--dry-rccl: rows of the fake database")
     ap.add_argument("--c1-cpu-vectors", type=int, default=256,
@@ -942,9 +993,35 @@ def main():
                     out[key] = fn()
                 except Exception as e:                        # noqa: BLE001
                     out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        pmc_box, pmc_thread = {}, None
+        if world == 1 and not args.no_pmc and K > 0:
+            # roofline.traffic of this command, measured now: the two PMC passes run as child processes on the (idle) GPU while
+            # this process times the CPU baseline on the host cores
+            import threading
+            pmc_thread = threading.Thread(target=lambda: pmc_box.update(pmc_traffic_live(args)), daemon=True)
+            pmc_thread.start()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if pmc_thread is not None:
+            pmc_thread.join(600)
+            if pmc_box.get("ok"):
+                rf["traffic"] = pmc_box["bytes_per_launch"]
+                rf["traffic_unit"] = ("bytes per launch of the dominant kernel, L2<->fabric (Infinity-Cache hits included): MEASURED for this command by "
+                                      "two rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE; child processes of this run, "
+                                      "untimed, same workload and batch, mean over the full-size launches)")
+                rf["traffic_passes"] = pmc_box["passes"]
+                # algorithmic bytes of one launch (SURVEY 8d / DESIGN 5): every (vector, beam) group's xhat row read once, every
+                # vector's x once, the step's weights once (2 FLOP per weight per row -> bytes = 2 x FLOP per row), the B winners
+                # (xhat row + history) written once
+                groups, vecs = rows_per_launch / max(cfg.A, 1), rows_per_launch / max(cfg.A * cfg.B, 1)
+                alg = groups * cfg.D * 4 + vecs * cfg.D * 4 + 2.0 * mlp_row + groups * (cfg.D * 4 + 4 * cfg.M_total)
+                rf["algorithmic_bytes_per_launch"] = alg
+                rf["traffic_over_algorithmic_bytes"] = pmc_box["bytes_per_launch"] / alg
+                rf["traffic_GBps"] = pmc_box["bytes_per_launch"] / (pmc_box["passes"]["FETCH_SIZE"]["mean_duration_us"] * 1e-6) / 1e9
+                rf["traffic_measure_seconds"] = pmc_box.get("seconds")
+            else:
+                rf["traffic_live_error"] = pmc_box.get("error", "the PMC passes did not finish")
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:

@@ -101,8 +101,12 @@ struct KnnFilt {
 // `s_waitcnt vmcnt(0)` in the loop, each draining the fragment ring, and 268 registers = one wave per SIMD).  The list
 // (about 130 entries over a wave's life at k = 100) is flushed to the per-query lists in HBM when it could overflow and at
 // the end: one returning atomic per entry, 64 entries per wait.
+constexpr int kKnnLdsNeeded = 4096 * 4 + kKnnCap * 8 + 64;   // knn_select_kernel: hist + buf (+ scalars): the largest static LDS here
+static_assert(kKnnLdsNeeded <= 160 * 1024, "the selection kernels' LDS must fit a gfx950 CU");
 constexpr int kKnnMaxChunk = 4096;   // query rows per chunk (qinco_knn_search): thresholds in LDS
 constexpr int kKnnWaveList = 512;    // entries of a wave's survivor list (room for 4 x 64 checked once per 8 query rows).
+static_assert(2 * ((kKnnMaxChunk + 32) * 8 + 4 * kKnnWaveList * 12) <= 160 * 1024,
+              "knn_table_kernel<D, true> is launched for two workgroups per CU (waves_per_eu(2)): both residents' LDS must fit");
 // Two workgroups per CU = two waves per SIMD, measured: one wave per SIMD (lists of 2048 entries = 128 KiB of LDS) 27.4 -> 33.3 ms.
 // Per-wave cycle stamps (scripts/exp_knn_timeline.py): a wave needs ~545 cycles per 4-MFMA step of this loop (256 of matrix pipe)
 // when it has its SIMD nearly to itself in the launch's tail and ~640 when it shares it -- the pipe is 0.80 busy inside the loop.

@@ -1840,6 +1840,14 @@ static int scratch_leave(qinco_handle_s* h, hipStream_t st) {
   return 0;
 }
 
+// (the host forms: whatever way they return -- an error between two passes included -- the work they enqueued on their private
+// stream is recorded as the scratch's last user, so the next call on another stream waits for it)
+struct ScratchLeaveOnExit {
+  qinco_handle_s* h;
+  hipStream_t st;
+  ~ScratchLeaveOnExit() { (void)scratch_leave(h, st); }
+};
+
 extern "C" int qinco_encode(qinco_handle h, const void* x, int x_dtype, int64_t stride, int64_t n, void* codes_out,
                             int code_dtype, float* xhat_out, int flags, void* stream) {
   int rc = check_common(h, x, codes_out, n, code_dtype, "qinco_encode");
@@ -2005,6 +2013,7 @@ extern "C" int qinco_encode_host(qinco_handle h, const void* x, int x_dtype, int
   // the private compute stream is non-blocking: it is ordered behind earlier device-pointer calls on this handle (torch's stream,
   // the null stream) explicitly -- they work in the same scratch and raise the same flag
   if ((rc = scratch_enter(h, p.s_comp))) return rc;
+  ScratchLeaveOnExit leave{h, p.s_comp};
   // this call reports its own work only: a flag left behind by an unchecked device-pointer call is dropped
   if (h->split16) HIP_TRY(hipMemsetAsync(h->err_flag, 0, sizeof(int), p.s_comp));
   const int64_t P = (n + pass - 1) / pass;
@@ -2086,6 +2095,7 @@ extern "C" int qinco_decode_host(qinco_handle h, const void* codes, int code_dty
   if ((rc = ensure_decode_scratch(h, cap))) return rc;
   HostPipe& p = *h->pipe;
   if ((rc = scratch_enter(h, p.s_comp))) return rc;   // (see qinco_encode_host)
+  ScratchLeaveOnExit leave{h, p.s_comp};
   // this call reports its own codes only: a flag left behind by an unchecked device-pointer decode is dropped
   HIP_TRY(hipMemsetAsync(h->err_flag, 0, sizeof(int), p.s_comp));
   const int64_t P = (n + pass - 1) / pass;

@@ -64,6 +64,15 @@ extern "C" int qinco_knn_create(int32_t D, qinco_knn* out) {
     delete s;
     return fail(QINCO_ERR_HIP, "hipGetDevice failed (no HIP device?)");
   }
+  // knn_select_kernel / knn_cand_select_kernel hold 80 KiB of static LDS (histogram + the 8192-key buffer) and two workgroups of
+  // knn_table_kernel<D, true> (57 KiB each) share a CU: a 160 KiB-LDS part (gfx950).  This library is built for gfx950 only; the
+  // check turns a launch failure on anything else into a message.
+  int lds = 0;
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, s->device) != hipSuccess || lds < kKnnLdsNeeded) {
+    delete s;
+    return fail(QINCO_ERR_UNSUPPORTED, "qinco_knn_create: the search kernels need %d KiB of LDS per workgroup, this device offers %d KiB",
+                kKnnLdsNeeded >> 10, lds >> 10);
+  }
   *out = s;
   return QINCO_OK;
 }
@@ -156,6 +165,7 @@ extern "C" int qinco_knn_search(qinco_knn s, const float* db, int64_t n, const f
   const long q_bytes = s->q_stream_bytes ? s->q_stream_bytes : (D >= 512 ? (long)2 << 20 : (long)1 << 20);
   const long l2_rows = q_bytes / (D * 4) / 32 * 32;
   if (chunk > l2_rows) chunk = l2_rows;
+  if (chunk < 32) chunk = 32;   // (a query_bytes below one 32-row block of this D -- 4096 B at D >= 64 -- must not give 0 rows)
   const long nq_pad = (nq + 31) / 32 * 32;
   if (chunk > nq_pad) chunk = nq_pad;
   int rc;

@@ -289,6 +289,8 @@ class PartFileWriter:
     def add(self, codes: np.ndarray):
         codes = np.ascontiguousarray(codes, dtype="<i8")
         assert codes.ndim == 2 and codes.shape[1] == self.M and self._seen + len(codes) <= self.rows
+        if len(codes) == 0:          # (nothing to append: in particular the deflate stream a last add() has closed stays closed)
+            return
         self._seen += len(codes)
         self._buf += codes.tobytes()
         self._finished = False

@@ -2,9 +2,21 @@
 
 `QINCoHIP` exposes the surface that qinco_tasks / search_tasks use on a QINCo / QINCoInferenceWrapper
 (SURVEY.md 8b): model(x, step="encode") -> (M, N) int64, model(codes, step="decode") -> (N, D) float32,
-.encode(x_norm) -> (codes_MB, xhat_BD), .decode(codes_MB), .built / .build(), .load_state_dict(sd), .eval(),
-.to(device), .data_mean / .data_std, get_codebooks_refs(), .qinco_model.steps[0].ivf_centroids.weight.  All arithmetic runs in libqinco_hip (HIP, gfx950);
-there is no CPU implementation behind this class.
+.encode(x_norm) -> (codes_MB, xhat_BD), .decode(codes_MB), .built / .build(), .load_state_dict(sd), .state_dict(), .eval(), .train(),
+.to(device), .data_mean / .data_std, get_codebooks_refs(), .qinco_model.steps[0].ivf_centroids.weight.  All arithmetic runs in
+libqinco_hip (HIP, gfx950); there is no CPU implementation behind this class.
+
+Container in = container out, like the reference's module (qinco_inference.py:272-283):
+  * torch CUDA tensor -> torch CUDA tensor on the same device (device pointers straight into the C ABI, asynchronous on the current
+    stream);
+  * torch CPU tensor -> torch CPU tensor (the reference's `cfg.cpu=true` callers -- task=eval_time asserts cpu,
+    qinco_tasks.py:487-492 -- index the result and call `.cpu()` / `.item()` on it, qinco_tasks.py:101-125; the vectors travel to
+    the GPU through the pinned host pipeline of qinco_encode_host / qinco_decode_host);
+  * numpy array -> numpy array.
+When torch is importable the class IS a torch.nn.Module (without parameters: the weights live in the handle's device memory), so
+`accelerator.prepare(model)` (qinco_tasks.py:499-505), `unwrap(model)` (qinco/utils.py:230-237), `.eval()`, `.train()`, `.to(...)`,
+`torch.no_grad` / `inference_mode` blocks and forward hooks all behave as they do for the reference's model; without torch it is a
+plain object with the same methods.
 """
 from __future__ import annotations
 
@@ -16,10 +28,41 @@ from .checkpoint import load_checkpoint, state_dict_to_numpy
 from .config import QincoConfig
 from .engine import QincoEngine, _is_torch
 
+try:                                    # the Module face needs torch; the arithmetic does not
+    import torch as _torch
+    _Base = _torch.nn.Module
+except ImportError:                     # pragma: no cover -- this image always has torch
+    _torch = None
 
-class QINCoHIP:
+    class _Base:                        # the handful of Module methods the reference's callers use
+        training = False
+
+        def __call__(self, *a, **kw):
+            return self.forward(*a, **kw)
+
+        def eval(self):
+            self.training = False
+            return self
+
+        def train(self, mode: bool = True):
+            self.training = bool(mode)
+            return self
+
+        def to(self, *a, **kw):
+            return self
+
+
+def _host_like(arg, out):
+    """A host result in the container the caller passed: torch CPU tensor for a torch CPU tensor, numpy otherwise."""
+    if _torch is not None and _is_torch(arg) and not arg.is_cuda and isinstance(out, np.ndarray):
+        return _torch.from_numpy(out)
+    return out
+
+
+class QINCoHIP(_Base):
     def __init__(self, cfg: QincoConfig, state_dict: Optional[dict] = None, max_batch: int = 8192,
                  device: Optional[int] = None, split_f16: bool = False):
+        super().__init__()
         self.cfg = cfg
         self.max_batch = max_batch
         self.device = device
@@ -36,10 +79,18 @@ class QINCoHIP:
         cfg, sd = load_checkpoint(path, A, B)
         return cls(cfg, sd, **kw)
 
-    def load_state_dict(self, state_dict: dict, **_):
+    def load_state_dict(self, state_dict: dict, *_, **__):
         """QINCoInferenceWrapper.load_state_dict: load, then rebuild (qinco_inference.py:285-288)."""
         self._sd = state_dict_to_numpy(state_dict)
         self.build()
+
+    def state_dict(self, *_, **__):
+        """The weights as loaded (tensors when torch is here): what `save_model` (qinco/utils.py) would write back."""
+        if self._sd is None:
+            return {}
+        if _torch is None:
+            return dict(self._sd)
+        return {k: _torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else _torch.as_tensor(v) for k, v in self._sd.items()}
 
     def build(self):
         if self._sd is None:
@@ -74,10 +125,15 @@ class QINCoHIP:
             steps.append(st)
         return NS(steps=steps)
 
-    def eval(self):
-        return self
-
-    def to(self, device=None):
+    def to(self, *args, **kwargs):
+        """A no-op that returns the model (the handle is bound to the GPU it was created on; qinco_inference.py:303's `.to(device)`
+        and accelerate's device placement both land here).  Asking for another GPU than the handle's is refused."""
+        dev = args[0] if args else kwargs.get("device")
+        if _torch is not None and isinstance(dev, (str, _torch.device)):
+            dev = _torch.device(dev)
+            if dev.type == "cuda" and dev.index is not None and self.engine is not None and self.engine.device is not None \
+                    and dev.index != self.engine.device:
+                raise ValueError(f"QINCoHIP lives on cuda:{self.engine.device}; build another one on {dev} (QINCoHIP(..., device={dev.index}))")
         return self
 
     def set_search(self, A: Optional[int] = None, B: Optional[int] = None):
@@ -98,16 +154,14 @@ class QINCoHIP:
         return refs
 
     # ---- forward --------------------------------------------------------------------------------
-    def __call__(self, x_in, *args, step: str = "train", **kwargs):
+    def forward(self, x_in, *args, step: str = "train", **kwargs):
         """QINCoInferenceWrapper.forward (qinco_inference.py:272-283)."""
         assert step in ["encode", "decode"]
         if not self.built:
             raise RuntimeError("model not built")
         if step == "encode":
-            return self._t(self.engine.encode(x_in))
-        return self.engine.decode(self._t(x_in))
-
-    forward = __call__
+            return self._t(_host_like(x_in, self.engine.encode(x_in)))
+        return _host_like(x_in, self.engine.decode(self._t(x_in)))
 
     @staticmethod
     def _t(a):
@@ -117,8 +171,8 @@ class QINCoHIP:
     def encode(self, x_norm):
         """QINCoInferenceWrapper.encode(x_target_BD) -> (codes_MB, xhat_BD), both in normalised space (:340-350)."""
         codes, xhat = self.engine.encode(x_norm, return_xhat=True, normalised=True)
-        return self._t(codes), xhat
+        return self._t(_host_like(x_norm, codes)), _host_like(x_norm, xhat)
 
     def decode(self, codes_MB):
         """QINCoInferenceWrapper.decode(codes_MB) -> normalised reconstruction (:330-337)."""
-        return self.engine.decode(self._t(codes_MB), normalised=True)
+        return _host_like(codes_MB, self.engine.decode(self._t(codes_MB), normalised=True))

@@ -220,6 +220,19 @@ def test_part_file_writer_is_the_reference_format(tmp_path):
         got = np.load(p)["codes"]
         assert got.dtype == np.int64 and got.shape == c.shape and np.array_equal(got, c)
         assert zipfile.ZipFile(p).testzip() is None and zipfile.ZipFile(p).namelist() == ["codes.npy"]
+    # an empty batch behind the last rows (a producer that flushes once more) leaves the closed deflate stream alone
+    c = rs.randint(0, 256, (3000, 8)).astype(np.int64)
+    p = str(tmp_path / "tail.npz")
+    w = PartFileWriter(p, 3000, 8, threads=2)
+    w.add(c)
+    w.add(c[:0])
+    w.close()
+    raw = open(p, "rb").read()
+    w2 = PartFileWriter(str(tmp_path / "tail2.npz"), 3000, 8, threads=2)
+    w2.add(c)
+    w2.close()
+    assert raw == open(tmp_path / "tail2.npz", "rb").read() and np.array_equal(np.load(p)["codes"], c)
+    assert zipfile.ZipFile(p).testzip() is None
     model = OracleModel("tiny_proj_beam")
     from qinco_amd import synth_vectors
     db = synth_vectors(model.cfg, model.sd, 130, seed=2)

@@ -257,6 +257,33 @@ def test_knn_filtered_form_falls_back_on_the_device_when_a_list_overflows():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", [128, 768, 32])
+def test_knn_smallest_query_stream_option(D):
+    """QINCO_KNN_OPT_QUERY_BYTES at its documented minimum (4096 B): less than one 32-row block of query fragments for D >= 64 --
+    the chunk must come out as 32 rows, not 0 (round-5 review: a division by zero), and the ids must not depend on the chunking."""
+    import torch
+    from qinco_amd import _lib
+    from qinco_amd.search import KnnSearcher
+    rs = np.random.RandomState(D)
+    db = torch.from_numpy(rs.randn(70_000, D).astype(np.float32)).cuda()
+    q = torch.from_numpy(rs.randn(100, D).astype(np.float32)).cuda()
+    outs = []
+    for qb in (None, 4096):
+        knn = KnnSearcher(D)
+        if qb is not None:
+            _lib.check(knn.lib.qinco_knn_set_option(knn._h, 2, qb))
+        ids, dist = knn.search(db, q, k=10, return_dist=True)
+        outs.append((ids.cpu().numpy(), dist.cpu().numpy(), knn.last_stats()))
+        knn.close()
+    assert outs[1][2]["chunks"] == 4 and outs[0][2]["chunks"] == 1              # 100 queries in chunks of 32
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+    knn = KnnSearcher(D)
+    with pytest.raises(ValueError):
+        _lib.check(knn.lib.qinco_knn_set_option(knn._h, 2, 4095))
+    knn.close()
+
+
+@pytest.mark.gpu
 def test_knn_argument_errors_and_empty():
     from qinco_amd.search import KnnSearcher
     with pytest.raises(NotImplementedError):

@@ -275,8 +275,15 @@ QINCO_API int qinco_knn_search(qinco_knn knn, const float* db, int64_t n, const 
 #define QINCO_KNN_OPT_FILTER 0
 #define QINCO_KNN_OPT_FILTER_MIN_N 1
 #define QINCO_KNN_OPT_QUERY_BYTES 2   /* bytes of query rows per chunk (default 1 MiB: the chunk's fragments stay in L2), <= 4096 rows */
+#define QINCO_KNN_OPT_ROLES 3         /* 0 (default): every wave computes and filters (knn_table_kernel<D, true>); 1: D <= 128 runs the
+                                         filtered table as one MFMA wave + one filter wave per SIMD (csrc/knn_roles_kernel.hpp) -- the
+                                         round-6 experiment, measured slower, kept selectable.  Same candidate sets, same
+                                         result bits either way. */
 QINCO_API int qinco_knn_set_option(qinco_knn knn, int32_t option, int64_t value);
 QINCO_API int qinco_knn_last_stats(qinco_knn knn, int64_t* out3);
+/* Of the two-role kernel's launches since the last call (synchronises the device): out2 = {workgroups whose eight waves covered
+ * all four SIMDs of their CU -- one MFMA wave per SIMD, taken by HW_ID --, workgroups that fell back to roles by wave index}. */
+QINCO_API int qinco_knn_roles_stats(qinco_knn knn, int64_t* out2);
 /* the same on host buffers; synchronous */
 QINCO_API int qinco_knn_search_host(qinco_knn knn, const float* db, int64_t n, const float* queries, int64_t nq, int32_t k,
                                     int64_t* ids_out, float* dist_out);

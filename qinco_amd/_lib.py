@@ -21,7 +21,7 @@ API_SYMBOLS = [
     "qinco_decode_host", "qinco_profile_enable", "qinco_profile_read", "qinco_profile_read2", "qinco_flops_per_vector_encode",
     "qinco_flops_per_vector_decode", "qinco_shape_supported", "qinco_last_error", "qinco_version",
     "qinco_lut_create", "qinco_lut_destroy", "qinco_lut_decode", "qinco_lut_decode_host",
-    "qinco_ivf_last_stats", "qinco_check", "qinco_selftest", "qinco_knn_create", "qinco_knn_destroy", "qinco_knn_search", "qinco_knn_search_host", "qinco_knn_set_option", "qinco_knn_last_stats", "qinco_sqerr_sum", "qinco_rerank",
+    "qinco_ivf_last_stats", "qinco_check", "qinco_selftest", "qinco_knn_create", "qinco_knn_destroy", "qinco_knn_search", "qinco_knn_search_host", "qinco_knn_set_option", "qinco_knn_last_stats", "qinco_knn_roles_stats", "qinco_sqerr_sum", "qinco_rerank",
 ]
 
 
@@ -144,6 +144,8 @@ def load() -> C.CDLL:
     lib.qinco_knn_search.argtypes = [vp, vp, i64, vp, i64, C.c_int32, vp, vp, vp]
     lib.qinco_knn_search_host.argtypes = [vp, vp, i64, vp, i64, C.c_int32, vp, vp]
     lib.qinco_knn_set_option.argtypes = [vp, C.c_int32, i64]
+    lib.qinco_knn_roles_stats.argtypes = [vp, C.POINTER(i64)]
+    lib.qinco_knn_roles_stats.restype = C.c_int
     lib.qinco_knn_last_stats.argtypes = [vp, C.POINTER(i64)]
     lib.qinco_sqerr_sum.argtypes = [vp, vp, i64, C.POINTER(dbl), vp]
     lib.qinco_rerank.argtypes = [vp, vp, i64, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp, vp, vp, vp]

@@ -83,6 +83,21 @@ __device__ __forceinline__ float knn_dist(float qn, float xn, float dot) {
   return d != d ? __builtin_bit_cast(float, 0x7fc00000u) : d;
 }
 
+// The same distance without the NaN rule, for the filter's threshold test only (a NaN fails `d <= t` whatever its sign).
+__device__ __forceinline__ float knn_dist_raw(float qn, float xn, float dot) {
+  return __fsub_rn(__fadd_rn(qn, xn), __fmul_rn(2.f, dot));
+}
+// The threshold the filter compares with, as a FLOAT: the distance whose key's high word is tau.  `d <= t` as floats keeps every
+// pair whose key is <= tau (the key order is the float order with -0 below +0: the float test can only keep MORE -- a +0 against a
+// threshold of -0 -- and the candidate sort orders by the full keys anyway).  A NaN threshold (fewer than k finite distances in the
+// sample) and the 0 of a padding row (-> a negative NaN) keep nothing: the list comes up short and the chunk is redone unfiltered,
+// as it is when the key test floods the list.  One v_cmp per pair instead of the five VALU instructions of the key: the matrix
+// pipe's f32 MFMAs and the VALU share the SIMD's fp32 lanes, so every filter instruction is a slot the chain does not get
+// (round 6: the two-role experiment).
+__device__ __forceinline__ float knn_tau_float(unsigned tau) {
+  return __builtin_bit_cast(float, (tau & 0x80000000u) ? (tau & 0x7fffffffu) : ~tau);
+}
+
 // The filtered form's arguments (FILT = true); `pred` also predicates the unfiltered form when it runs as the fall-back.
 struct KnnFilt {
   const unsigned* tau;        // per query row of the chunk: high word of the k-th smallest key of the sample
@@ -111,21 +126,22 @@ static_assert(2 * ((kKnnMaxChunk + 32) * 8 + 4 * kKnnWaveList * 12) <= 160 * 102
 // Per-wave cycle stamps (scripts/exp_knn_timeline.py): a wave needs ~545 cycles per 4-MFMA step of this loop (256 of matrix pipe)
 // when it has its SIMD nearly to itself in the launch's tail and ~640 when it shares it -- the pipe is 0.80 busy inside the loop.
 
-template <int D, bool FILT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 128 ? 2 : 1)))
+template <int D, bool FILT, int WPE = (D <= 128 ? 2 : 1)>   // WPE: waves per SIMD (1: the LDS lists are sized so that one workgroup fills a CU)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qnorm, int nqblocks,
                  const float* __restrict__ db, long N, long row_stride, float* __restrict__ table, long ldt, KnnFilt f) {
   constexpr int NDB = D / 32;
   if (!FILT && f.pred && *f.pred == 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
-  __shared__ uint2 s_qt[FILT ? kKnnMaxChunk + 32 : 1];   // per query row of the chunk: (|q|^2 bits, threshold key); rows >= nq_valid: (0, 0)
-  __shared__ unsigned long long s_key[FILT ? 4 : 1][FILT ? kKnnWaveList : 1];
-  __shared__ unsigned s_row[FILT ? 4 : 1][FILT ? kKnnWaveList : 1];
+  __shared__ uint2 s_qt[FILT ? kKnnMaxChunk + 32 : 1];   // per query row of the chunk: (|q|^2, threshold as a float: knn_tau_float) bits
+  constexpr int LIST = (FILT && WPE == 1 && D <= 128) ? 2 * kKnnWaveList : kKnnWaveList;   // (1024 entries: 81 KiB with the thresholds -> one workgroup per CU)
+  __shared__ unsigned long long s_key[FILT ? 4 : 1][FILT ? LIST : 1];
+  __shared__ unsigned s_row[FILT ? 4 : 1][FILT ? LIST : 1];
   if constexpr (FILT) {
     // a padding row's fragments and norm are 0: its distances are |x|^2 >= 0, keys >= 0x80000000 -- above a threshold of 0
     for (int i = threadIdx.x; i < nqblocks * 32; i += 256)
-      s_qt[i] = make_uint2(__builtin_bit_cast(unsigned, qnorm[i]), i < f.nq_valid ? f.tau[i] : 0u);
+      s_qt[i] = make_uint2(__builtin_bit_cast(unsigned, qnorm[i]), __builtin_bit_cast(unsigned, knn_tau_float(i < f.nq_valid ? f.tau[i] : 0u)));
     __syncthreads();
   }
   const long n0 = ((long)blockIdx.x * 4 + wave) * 32;
@@ -216,14 +232,15 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
     auto filt = [&](const f32x16& prev, const int pq, const int v) __attribute__((always_inline)) {
       const int g = v >> 2, e = v & 3;
       const uint2* qp = s_qt + pq * 32 + 4 * half;
-      if (e == 0 && lcount + 256 > kKnnWaveList) flush();
+      if (e == 0 && lcount + 256 > LIST) flush();
       const uint2 qt = qt_nxt;
       qt_nxt = v < 15 ? qp[8 * ((v + 1) >> 2) + ((v + 1) & 3)] : qp[32];   // (slice 0 of the next block; s_qt has a block of slack)
-      const unsigned u = knn_key_hi(knn_dist(__builtin_bit_cast(float, qt.x), xn, prev[v]));
-      const bool pass = valid && u <= qt.y;
+      const float d = knn_dist_raw(__builtin_bit_cast(float, qt.x), xn, prev[v]);
+      const bool pass = valid && d <= __builtin_bit_cast(float, qt.y);   // (the threshold as a float: knn_tau_float)
       const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
       if (m) {  // uniform
-        if (pass) {
+        if (pass) {   // (d is not a NaN here: its key needs no NaN rule)
+          const unsigned u = knn_key_hi(d);
           const int p = lcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
           s_key[wave][p] = ((unsigned long long)u << 32) | (unsigned)(n0 + j);
           s_row[wave][p] = (unsigned)(pq * 32 + 8 * g + 4 * half + e);

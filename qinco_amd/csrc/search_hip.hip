@@ -8,6 +8,7 @@
 
 #include "abi_util.hpp"
 #include "knn_kernel.hpp"
+#include "knn_roles_kernel.hpp"
 #include "rerank_kernel.hpp"
 
 using namespace qinco;
@@ -31,6 +32,8 @@ struct qinco_knn_s {
   long last_chunks = 0, last_filtered = 0;   // of the last search: chunks, chunks that took the filtered form
   int filter_mode = 1;       // 0: never, 1: where it pays (n >= filter_min_n and a sampling stride >= 4)
   long filter_min_n = 65536;
+  int roles_mode = 0;        // opt-in: the filtered table as knn_table_roles_kernel (MFMA waves + filter waves) where D <= 128
+  int* roles_stat = nullptr; // {workgroups whose waves covered all four SIMDs, workgroups that fell back to index roles}
   long q_stream_bytes = 0;   // query fragments of one chunk: every wave walks them, they should stay in L2 (0: 1 MiB, 2 MiB for D >= 512)
   // staging for the host form
   void* s_db = nullptr;
@@ -73,14 +76,30 @@ extern "C" int qinco_knn_create(int32_t D, qinco_knn* out) {
     return fail(QINCO_ERR_UNSUPPORTED, "qinco_knn_create: the search kernels need %d KiB of LDS per workgroup, this device offers %d KiB",
                 kKnnLdsNeeded >> 10, lds >> 10);
   }
+  if (hipMalloc((void**)&s->roles_stat, 2 * sizeof(int)) != hipSuccess || hipMemset(s->roles_stat, 0, 2 * sizeof(int)) != hipSuccess) {
+    delete s;
+    return fail(QINCO_ERR_HIP, "qinco_knn_create: hipMalloc failed");
+  }
   *out = s;
+  return QINCO_OK;
+}
+
+extern "C" int qinco_knn_roles_stats(qinco_knn s, int64_t* out2) {
+  if (!s || !out2) return fail(QINCO_ERR_INVALID, "qinco_knn_roles_stats: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipDeviceSynchronize());
+  int h[2] = {0, 0};
+  HIP_TRY(hipMemcpy(h, s->roles_stat, sizeof(h), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(s->roles_stat, 0, sizeof(h)));
+  out2[0] = h[0];
+  out2[1] = h[1];
   return QINCO_OK;
 }
 
 extern "C" int qinco_knn_destroy(qinco_knn s) {
   if (!s) return QINCO_OK;
   (void)hipDeviceSynchronize();
-  for (void* p : {(void*)s->qstream, (void*)s->qnorm, (void*)s->table, (void*)s->cand, (void*)s->tau, (void*)s->ovf, s->s_db, s->s_q,
+  for (void* p : {(void*)s->qstream, (void*)s->qnorm, (void*)s->table, (void*)s->cand, (void*)s->tau, (void*)s->ovf, (void*)s->roles_stat, s->s_db, s->s_q,
                   s->s_ids, s->s_dist})
     if (p) (void)hipFree(p);
   delete s;
@@ -91,6 +110,12 @@ template <int D>
 static void launch_table_d(qinco_knn_s* s, int nqblocks, const float* db, long n, long stride, long ldt, bool filt, const KnnFilt& f,
                            hipStream_t st) {
   const dim3 grid((unsigned)((n + 127) / 128));
+  if constexpr (D <= 128) {
+    if (filt && s->roles_mode && stride == 1) {
+      hipLaunchKernelGGL((knn_table_roles_kernel<D>), grid, dim3(512), 0, st, s->qstream, s->qnorm, nqblocks, db, n, f, s->roles_stat);
+      return;
+    }
+  }
   if (filt)
     hipLaunchKernelGGL((knn_table_kernel<D, true>), grid, dim3(256), 0, st, s->qstream, s->qnorm, nqblocks, db, n, stride, s->table, ldt, f);
   else
@@ -121,6 +146,7 @@ extern "C" int qinco_knn_set_option(qinco_knn s, int32_t option, int64_t value) 
       if (value < 1) return fail(QINCO_ERR_INVALID, "qinco_knn_set_option: filter_min_n must be >= 1");
       s->filter_min_n = (long)value;
       return QINCO_OK;
+    case QINCO_KNN_OPT_ROLES: s->roles_mode = value != 0; return QINCO_OK;
     case QINCO_KNN_OPT_QUERY_BYTES:
       if (value < 4096) return fail(QINCO_ERR_INVALID, "qinco_knn_set_option: query_bytes must be >= 4096");
       s->q_stream_bytes = (long)value;

@@ -20,9 +20,11 @@ F32 = np.float32
 class KnnSearcher:
     """ids[q] = argsort_n(|queries[q]|^2 + |db[n]|^2 - 2 queries[q].db[n])[:k]  (stable: ties -> lower n)."""
 
-    def __init__(self, D: int, filtered: bool = True, filter_min_n: int | None = None):
+    def __init__(self, D: int, filtered: bool = True, filter_min_n: int | None = None, roles: bool | None = None):
         """filtered: large databases take the form that never writes the (queries x n) distance table (csrc/knn_kernel.hpp;
-        the same ids and distances bit for bit); filter_min_n: the smallest n that takes it (library default 65536)."""
+        the same ids and distances bit for bit); filter_min_n: the smallest n that takes it (library default 65536);
+        roles: None = library default (off): every wave computes and filters; True (D <= 128): the filtered table runs as one MFMA
+        wave + one filter wave per SIMD (csrc/knn_roles_kernel.hpp: the round-6 experiment, measured slower).  Same bits either way."""
         self.lib = _lib.load()
         self.D = int(D)
         self._h = C.c_void_p()
@@ -30,6 +32,15 @@ class KnnSearcher:
         _lib.check(self.lib.qinco_knn_set_option(self._h, 0, int(bool(filtered))))
         if filter_min_n is not None:
             _lib.check(self.lib.qinco_knn_set_option(self._h, 1, int(filter_min_n)))
+        if roles is not None:
+            _lib.check(self.lib.qinco_knn_set_option(self._h, 3, int(bool(roles))))
+
+    def roles_stats(self) -> dict:
+        """Two-role kernel launches since the last call (synchronises): workgroups with one MFMA wave on every SIMD / that fell
+        back to roles by wave index."""
+        out = (C.c_int64 * 2)()
+        _lib.check(self.lib.qinco_knn_roles_stats(self._h, out))
+        return {"spread": int(out[0]), "by_index": int(out[1])}
 
     def last_stats(self) -> dict:
         """Of the last search (synchronises the device): chunks of queries, those that took the filtered form, those redone

@@ -121,26 +121,30 @@ def knn_rate():
         db = torch.randn(N, D, device=dev, generator=g)
         q = torch.randn(Q, D, device=dev, generator=g)
         got = {}
-        for filtered in (True, False):
-            knn = KnnSearcher(D, filtered=filtered)
+        for form, filtered, roles in (("filtered", True, False), ("filtered, two roles (opt-in)", True, True), ("table", False, False)):
+            if roles and D > 128:
+                continue
+            knn = KnnSearcher(D, filtered=filtered, roles=roles)
             if os.environ.get("KNN_QUERY_BYTES"):
                 knn.lib.qinco_knn_set_option(knn._h, 2, int(os.environ["KNN_QUERY_BYTES"]))
             knn.search(db, q, k=100)   # warm-up at the full shape (allocates the scratch)
             torch.cuda.synchronize()
+            knn.roles_stats()
             best = 1e9
             for _ in range(3):
                 t0 = time.perf_counter()
                 ids = knn.search(db, q, k=100)
                 torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
-            got[filtered] = ids
-            print(json.dumps({"workload": f"knn top-100 N={N} Q={Q} D={D}", "form": "filtered" if filtered else "table",
+            got[form] = ids
+            print(json.dumps({"workload": f"knn top-100 N={N} Q={Q} D={D}", "form": form,
                               "seconds": best, "queries_per_s": Q / best, "table_tflops": 2.0 * D * N * Q / best / 1e12,
                               "frac_fp32_mfma": 2.0 * D * N * Q / best / 1e12 / PEAK, "pairs_per_s": N * Q / best,
-                              **knn.last_stats()}), flush=True)
+                              **knn.last_stats(), "role_workgroups": knn.roles_stats()}), flush=True)
             knn.close()
             assert ids.shape == (Q, 100)
-        assert torch.equal(got[True], got[False]), "filtered form differs from the table form"
+        for form in got:
+            assert torch.equal(got[form], got["table"]), f"{form} differs from the table form"
         del db, q, got
 
 

@@ -155,18 +155,28 @@ def test_knn_exact_ties_resolve_to_lower_index_and_radix_refinement():
 
 
 def _knn_both_forms(D, db, q, k, min_n=1024):
-    """The same search through the filtered form (forced from min_n rows on) and the unfiltered form: ids and distances."""
+    """The same search through the filtered form (forced from min_n rows on) and the unfiltered form: ids and distances.  The
+    filtered form runs twice where it has two kernels (D <= 128): every wave in both roles (the default) and one MFMA wave + one
+    filter wave per SIMD (opt-in, csrc/knn_roles_kernel.hpp) -- the two must agree bit for bit before the first is handed back."""
     import torch
     from qinco_amd.search import KnnSearcher
     dbt, qt = torch.from_numpy(db).cuda(), torch.from_numpy(q).cuda()
     out = []
-    for filtered in (True, False):
-        knn = KnnSearcher(D, filtered=filtered, filter_min_n=min_n)
+    for filtered, roles in ((True, None), (True, True), (False, None)):
+        knn = KnnSearcher(D, filtered=filtered, filter_min_n=min_n, roles=roles)
         ids, dist = knn.search(dbt, qt, k=k, return_dist=True)
         st = knn.last_stats()
+        st["role_workgroups"] = knn.roles_stats()
         out.append((ids.cpu().numpy(), dist.cpu().numpy(), st))
         knn.close()
-    return out
+    (ids_s, dist_s, st_s), (ids_r, dist_r, st_r) = out[0], out[1]
+    assert np.array_equal(ids_r, ids_s) and np.array_equal(dist_r.view(np.uint32), dist_s.view(np.uint32)), "two-role kernel differs"
+    assert {k_: v for k_, v in st_r.items() if k_ != "role_workgroups"} == {k_: v for k_, v in st_s.items() if k_ != "role_workgroups"}
+    ran_roles = sum(st_r["role_workgroups"].values())
+    assert (ran_roles > 0) == (D <= 128 and st_r["filtered"] > 0) and sum(st_s["role_workgroups"].values()) == 0, (st_r, st_s)
+    for o in out:
+        o[2].pop("role_workgroups")
+    return [out[0], out[2]]
 
 
 @pytest.mark.gpu

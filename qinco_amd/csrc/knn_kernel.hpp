@@ -172,6 +172,16 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
   f32x4 ring[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) ring[i] = wp[i * 64];
+  // the ring's loads are BUFFER loads (round 6, see the filtered form below): lane offset in a VGPR, fragment offset in an SGPR
+  const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(qstream), 0, 0x7fffffff, 0x00020000);
+  const int voff = lane * 16;
+  int soff = 0;   // byte offset of the current block's first fragment in the stream (uniform)
+  auto ring_load = [&](const int frag) __attribute__((always_inline)) -> f32x4 {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // (four fragments share one scalar offset: the 1 KiB steps inside a 4 KiB group ride in the instruction's 12-bit immediate)
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, voff + (frag & 3) * 1024, soff + (frag >> 2) * 4096, 0);
+    return __builtin_bit_cast(f32x4, r);
+  };
   float* tp = table + n0 + j;
   int lcount = 0;  // entries of this wave's survivor list (uniform)
   auto flush = [&]() __attribute__((always_inline)) {
@@ -198,7 +208,7 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
       for (int q = 0; q < 4; ++q) {
         const int i = ib * 4 + q;
         const f32x4 w = ring[i % P];
-        ring[i % P] = wp[(i + P) * 64];
+        ring[i % P] = ring_load(i + P);
         // fences: without them hipcc sinks each ring load down to its use one block later (a vmcnt(0) every 4 MFMAs),
         // or hoists the block's 64 MFMAs above all of its loads
         asm volatile("" ::: "memory");
@@ -208,7 +218,7 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], xt[ib][4 * q + e], acc, 0, 0, 0);
       }
     }
-    wp += NF * 64;
+    soff += NF * 1024;
     // lane holds queries qb*32 + 8g + 4*half + e of database row n0 + j
     if (valid) {
 #pragma unroll
@@ -228,24 +238,51 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
     // (|q|^2, threshold) of the NEXT slice is read from LDS while the current one is filtered: a per-wave timeline of the first
     // pipelined version showed 590 cycles per 4-MFMA step (256 ideal) with the slice's own `ds_read` + `lgkmcnt(0)` between the
     // step's first and second MFMA -- in-order issue held the chain behind the LDS round trip.
-    uint2 qt_nxt = s_qt[4 * half];
-    auto filt = [&](const f32x16& prev, const int pq, const int v) __attribute__((always_inline)) {
-      const int g = v >> 2, e = v & 3;
-      const uint2* qp = s_qt + pq * 32 + 4 * half;
-      if (e == 0 && lcount + 256 > LIST) flush();
-      const uint2 qt = qt_nxt;
-      qt_nxt = v < 15 ? qp[8 * ((v + 1) >> 2) + ((v + 1) & 3)] : qp[32];   // (slice 0 of the next block; s_qt has a block of slack)
-      const float d = knn_dist_raw(__builtin_bit_cast(float, qt.x), xn, prev[v]);
-      const bool pass = valid && d <= __builtin_bit_cast(float, qt.y);   // (the threshold as a float: knn_tau_float)
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-      if (m) {  // uniform
-        if (pass) {   // (d is not a NaN here: its key needs no NaN rule)
-          const unsigned u = knn_key_hi(d);
-          const int p = lcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-          s_key[wave][p] = ((unsigned long long)u << 32) | (unsigned)(n0 + j);
-          s_row[wave][p] = (unsigned)(pq * 32 + 8 * g + 4 * half + e);
+    // Round 6 -- every instruction of a wave that is not an MFMA takes the matrix pipe away from that wave's chain for its issue
+    // time (scripts/ubench/mfma_valu.hip: ~5 cycles per VALU instruction behind a dependent v_mfma_f32_32x32x2_f32, fully additive;
+    // only the OTHER wave of the SIMD can fill the gap, and only with an MFMA of its own).  Rounds 5's per-slice filter spent ~16
+    // such instructions per 4 MFMAs (ballot through v_cndmask + v_cmp_ne, a 64-bit VALU address per ring load, a branch and an LDS
+    // read per slice): 0.70-0.75 of the pipe.  Now: (a) the ring loads are BUFFER loads -- lane offset in one VGPR, the fragment's
+    // offset in an SGPR: one SALU add per load instead of three VALU instructions; (b) the filter of block qb - 1 runs as ONE burst
+    // behind the first fragment of block qb: 8 wide LDS reads, the 16 distances with packed adds / fmas, 16 compares straight into
+    // SGPR pairs (the ballot IS the compare's result), one branch.
+    const unsigned long long vmask = __builtin_amdgcn_ballot_w64(valid);
+    auto burst = [&](const f32x16& prev, const int pq) __attribute__((always_inline)) {
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {   // two halves of 8 slices (registers): slice v = 8 hb + 4 gg + e -> query row pq * 32 + 8 (2 hb + gg) + 4 half + e
+        uint2 qt[8];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const uint4* qp = reinterpret_cast<const uint4*>(s_qt + pq * 32 + 8 * (2 * hb + gg) + 4 * half);
+          const uint4 a = qp[0], b = qp[1];
+          qt[4 * gg + 0] = make_uint2(a.x, a.y);
+          qt[4 * gg + 1] = make_uint2(a.z, a.w);
+          qt[4 * gg + 2] = make_uint2(b.x, b.y);
+          qt[4 * gg + 3] = make_uint2(b.z, b.w);
         }
-        lcount += __popcll(m);
+        float d[8];
+        unsigned long long m[8];
+        unsigned long long any = 0;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          d[v] = knn_dist_raw(__builtin_bit_cast(float, qt[v].x), xn, prev[8 * hb + v]);
+          m[v] = __builtin_amdgcn_ballot_w64(d[v] <= __builtin_bit_cast(float, qt[v].y)) & vmask;   // (float threshold: knn_tau_float)
+          any |= m[v];
+        }
+        if (any) {  // uniform; none in 7 slices of 8
+#pragma unroll
+          for (int v = 0; v < 8; ++v) {
+            if ((v & 3) == 0 && lcount + 256 > LIST) flush();   // (room for 4 x 64 entries, checked once per 4 slices)
+            if (m[v]) {  // uniform
+              if ((m[v] >> lane) & 1) {   // (d is not a NaN here: its key needs no NaN rule)
+                const int p = lcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[v] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[v], 0u));
+                s_key[wave][p] = ((unsigned long long)knn_key_hi(d[v]) << 32) | (unsigned)(n0 + j);
+                s_row[wave][p] = (unsigned)(pq * 32 + 8 * (2 * hb + (v >> 2)) + 4 * half + (v & 3));
+              }
+              lcount += __popcll(m[v]);
+            }
+          }
+        }
       }
     };
     auto blockp = [&](const int qb, f32x16& acc, const f32x16& prev, auto have_prev) __attribute__((always_inline)) {
@@ -257,19 +294,21 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
         for (int q = 0; q < 4; ++q) {
           const int i = ib * 4 + q;
           const f32x4 w = ring[i % P];
-          ring[i % P] = wp[(i + P) * 64];
+          ring[i % P] = ring_load(i + P);
           asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], xt[ib][4 * q + e], acc, 0, 0, 0);
           if constexpr (decltype(have_prev)::value) {
-#pragma unroll
-            for (int v = (i * 16) / NF; v < ((i + 1) * 16) / NF; ++v) filt(prev, qb - 1, v);
+            if (i == 0) {
+              burst(prev, qb - 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
       }
-      wp += NF * 64;
+      soff += NF * 1024;
     };
     f32x16 acc0, acc1 = {};
     if constexpr (NDB <= 8) {
@@ -281,17 +320,14 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
       }
       if (qb < nqblocks) {
         blockp(qb, acc1, acc0, std::true_type{});
-#pragma unroll
-        for (int v = 0; v < 16; ++v) filt(acc1, qb, v);
+        burst(acc1, qb);
       } else {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) filt(acc0, qb - 1, v);
+        burst(acc0, qb - 1);
       }
     } else {  // D = 768: 384 registers of database rows leave no room for a second accumulator (12 spilled): filter behind the chain
       for (int qb = 0; qb < nqblocks; ++qb) {
         blockp(qb, acc0, acc1, std::false_type{});
-#pragma unroll
-        for (int v = 0; v < 16; ++v) filt(acc0, qb, v);
+        burst(acc0, qb);
       }
     }
     flush();

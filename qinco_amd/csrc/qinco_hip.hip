@@ -1011,9 +1011,15 @@ static int create_impl(const qinco_desc* desc, const qinco_weights* w, CreateOpt
   }
   const qinco_desc& d = dpad;
   const int ivf_real = desc->ivf_K;      // centroids the model has; d.ivf_K - ivf_real rows were added
-  if (d.K > 1024) return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: K=%d > 1024 not supported", d.K);
+  if (d.K > 1024)
+    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: K=%d > 1024 not supported -- a limit of this engine, not of the reference: its codebooks are "
+                "nn.Embedding(K, d) of any K (qinco_base.py:107, 229); the table / selection kernels here keep a codebook's K distances of "
+                "a group in one wave's registers and LDS lists, sized for K <= 1024 (every preset of the reference has K = 256)", d.K);
   if (d.A < 0 || d.A > d.K || d.B < 1) return fail(QINCO_ERR_INVALID, "qinco_create: need 0 <= A <= K and B >= 1");
-  if (d.ivf_K < 0 || d.ivf_K > (1 << 24)) return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: ivf_K=%d must be in [0, 2^24]", desc->ivf_K);
+  if (d.ivf_K < 0 || d.ivf_K > (1 << 24))
+    return fail(QINCO_ERR_UNSUPPORTED, "qinco_create: ivf_K=%d must be in [0, 2^24] -- a limit of this engine, not of the reference: IVFBook is "
+                "nn.Embedding(ivf_K, D) of any size (qinco_base.py:138-139); the assignment kernels here carry the centroid id in the low "
+                "24 bits of a (distance, id) key and int32 candidate lists (the reference's largest IVF has 2^20 centroids)", desc->ivf_K);
   if (d.ivf_K > 0 && d.M < 2) return fail(QINCO_ERR_INVALID, "qinco_create: an IVF model needs at least one QINCo step");
   if (d.ivf_K > 0 && d.A > 0 && d.B > d.K)
     return fail(QINCO_ERR_INVALID, "qinco_create: the first QINCo step of an IVF model pre-selects max(A, B) = %d of its K = %d codewords "

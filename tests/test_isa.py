@@ -187,15 +187,36 @@ def test_filtered_search_table_kernel_keeps_its_plan(kernels):
     workgroups' LDS within a CU's 160 KiB); the survivors go to the wave's LDS list by ballot + prefix count, so the only global
     atomics are the flush's (one inlined copy per 8 query rows of a block + the final one: 21), never one per (query, 32 rows) slice, and the MFMA loop holds
     no returning atomic in front of every slice -- the first version's 34 `s_waitcnt vmcnt(0)` in the loop."""
+    def find(prefix):
+        hits = [k for name, k in kernels.items() if name.startswith(prefix)]
+        assert len(hits) == 1, (prefix, [n for n in kernels if n.startswith(prefix)])
+        return hits[0]
     for D in (32, 64, 96, 128):
-        k = kernels[f"knn_table_kernel<{D},true>"]
+        k = find(f"knn_table_kernel<{D},true,2>")                  # (third argument: waves per SIMD)
         assert k.meta[".vgpr_count"] <= 256 and k.meta[".group_segment_fixed_size"] <= 80 * 1024, (D, k.meta)
         atomics = sum(x.startswith("global_atomic_add") for x in k.text)
         assert 1 <= atomics <= 24, (D, atomics)                    # (one per slice would be 16 per inlined block: 80)
         assert sum(x.startswith(("ds_write_b64", "ds_write2_b32", "ds_write2st64_b32")) for x in k.text) >= 16    # the wave-list appends
-    k = kernels["knn_table_kernel<128,true>"]
-    assert sum(isa.is_mfma(x) for x in k.text) == 64 * 4          # first block, two pipelined blocks per trip, remainder block
-    k = kernels["knn_table_kernel<128,false>"]
+    k = find("knn_table_kernel<128,true,2>")
+    mf = [i for i, x in enumerate(k.text) if isa.is_mfma(x)]
+    assert len(mf) == 64 * 4                                       # first block, two pipelined blocks per trip, remainder block
+    # Round 6 (every non-MFMA instruction of a wave costs its chain the issue time: scripts/ubench/mfma_valu.hip) -- the loop's diet:
+    # the ring is fed by buffer loads with scalar offsets (no 64-bit VALU address per load), the filter is one burst per block with
+    # the threshold test as ONE float compare per pair (16 per burst, 4 inlined bursts + the tail's) and no ballot through a VGPR
+    ops = [x.split()[0] for x in k.text]
+    assert sum(o == "buffer_load_dwordx4" for o in ops) >= 48 and sum(o == "global_load_dwordx4" for o in ops) <= 32, \
+        (sum(o == "buffer_load_dwordx4" for o in ops), sum(o == "global_load_dwordx4" for o in ops))
+    assert sum(o.startswith("v_cmp_le_f32") for o in ops) == 16 * 5      # (two bursts in the loop, the remainder block's, and the two tails)
+    body = k.text[mf[64]:mf[192]]                                  # the two pipelined blocks of the loop
+    steady = [x.split()[0] for x in body]
+    assert sum(o in ("v_add_co_u32_e32", "v_addc_co_u32_e32", "v_add_co_u32_e64", "v_addc_co_u32_e64") for o in steady) == 0, "a VALU address per ring load is back"
+    assert sum(o == "v_cmp_ne_u32_e32" for o in steady) == 0, "the ballot goes through a VGPR again"
+    assert sum(o == "ds_read_b128" for o in steady) >= 16          # thresholds: 8 wide LDS reads per burst, not one narrow read per slice
+    # the two-role form (opt-in): eight waves, one workgroup per CU by its LDS, the MFMA role's stream holds no VALU arithmetic
+    r = find("knn_table_roles_kernel<128>")
+    assert r.meta[".vgpr_count"] <= 256 and r.meta[".private_segment_fixed_size"] == 0 and r.meta[".group_segment_fixed_size"] > 80 * 1024
+    assert sum(isa.is_mfma(x) for x in r.text) == 64 * 4
+    k = find("knn_table_kernel<128,false")
     assert sum(x.startswith("global_atomic") for x in k.text) == 0
 
 

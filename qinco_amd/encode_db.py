@@ -474,7 +474,7 @@ def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None, code_
     sees it) and the seconds spent in the transfers.
 
     self_transfer: a job of ONE rank normally has nothing to move and returns its shard.  With self_transfer=True (and an
-    initialised process group) it runs the very same lines with rank 0 in both roles -- the all_reduce, then one grouped isend to
+    initialised process group whose payload group is on RCCL -- gloo cannot send to itself: ValueError) it runs the very same lines with rank 0 in both roles -- the all_reduce, then one grouped isend to
     itself + irecv from itself -- which is how a 1-GPU box executes this function on the real RCCL
     (tests/test_multi_gpu.py::test_torch_rccl_world_of_one, bench.py --gpus 1 --dry-rccl)."""
     import time
@@ -486,6 +486,8 @@ def gather_codes(codes_local: np.ndarray, db_size: int, dist, device=None, code_
     import torch
     if group is not None and dist.get_world_size(group) != world:
         raise ValueError("gather_codes: the payload group must span every rank of the job")
+    if loopback and str(dist.get_backend(group)) != "nccl":
+        raise ValueError("gather_codes(self_transfer=True) needs a payload group on RCCL (backend 'nccl'): gloo has no connection from a rank to itself")
     device = _comm_device(dist, device, group)
     t0 = time.perf_counter()
     M = codes_local.shape[1]

@@ -409,3 +409,35 @@ def test_rccl_id_file_is_matched_by_nonce_not_by_clock(tmp_path):
         c._exchange_through_file(2, f, 0.3, None)
     with pytest.raises(ValueError):
         RcclComm.__new__(RcclComm).__init__(0, 1)                           # neither an id nor a way to get one
+
+
+def test_gather_codes_self_transfer_needs_rccl():
+    """gather_codes(self_transfer=True): a job of one rank sends its shard to itself through the function's own transfer lines -- the
+    way a 1-GPU box executes them on RCCL (tests/test_multi_gpu.py).  gloo has no connection from a rank to itself: a clear error, not
+    gloo's 'Pair is not connected'; without a process group, or without the flag, one rank keeps returning its shard."""
+    import subprocess
+    import sys
+    from qinco_amd.encode_db import gather_codes
+    a = np.arange(40, dtype=np.int64).reshape(5, 8)
+    assert gather_codes(a, 5, None, self_transfer=True) is a                       # no process group: nothing to run through
+    code = """
+import sys, numpy as np, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from qinco_amd.encode_db import gather_codes
+dist.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:" + sys.argv[2])
+a = np.arange(40, dtype=np.int64).reshape(5, 8)
+assert gather_codes(a, 5, dist) is a
+try:
+    gather_codes(a, 5, dist, self_transfer=True)
+    print("NO ERROR")
+except ValueError as e:
+    print("ValueError:", e)
+dist.destroy_process_group()
+"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-c", code, str(ROOT), str(port)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ValueError: gather_codes(self_transfer=True) needs a payload group on RCCL" in r.stdout, r.stdout

@@ -91,9 +91,9 @@ __device__ __forceinline__ float knn_dist_raw(float qn, float xn, float dot) {
 // pair whose key is <= tau (the key order is the float order with -0 below +0: the float test can only keep MORE -- a +0 against a
 // threshold of -0 -- and the candidate sort orders by the full keys anyway).  A NaN threshold (fewer than k finite distances in the
 // sample) and the 0 of a padding row (-> a negative NaN) keep nothing: the list comes up short and the chunk is redone unfiltered,
-// as it is when the key test floods the list.  One v_cmp per pair instead of the five VALU instructions of the key: the matrix
-// pipe's f32 MFMAs and the VALU share the SIMD's fp32 lanes, so every filter instruction is a slot the chain does not get
-// (round 6: the two-role experiment).
+// as it is when the key test floods the list.  One v_cmp per pair instead of the five VALU instructions of the key: a wave is held
+// for the 16 passes of each of its f32 MFMAs and nothing of its own stream hides under them, so every filter instruction is issue
+// time its chain does not get (round 6: scripts/ubench/mfma_valu.hip).
 __device__ __forceinline__ float knn_tau_float(unsigned tau) {
   return __builtin_bit_cast(float, (tau & 0x80000000u) ? (tau & 0x7fffffffu) : ~tau);
 }
@@ -231,13 +231,10 @@ knn_table_kernel(const f32x4* __restrict__ qstream, const float* __restrict__ qn
     }
   };
   if constexpr (FILT) {
-    // Software pipeline inside the wave: while block qb's MFMA chain runs, the VALU filters block qb - 1's tile out of the
-    // other accumulator, one (query, 32 rows) slice behind every 64 / NF-th of the chain.  (First version: the filter behind
-    // its own block's chain -- the two waves of a SIMD start together and stay in step, so both were in their MFMA phase,
-    // then both in their ~700-instruction filter phase with the matrix pipe idle: 0.68 of the pipe at D = 128.)
-    // (|q|^2, threshold) of the NEXT slice is read from LDS while the current one is filtered: a per-wave timeline of the first
-    // pipelined version showed 590 cycles per 4-MFMA step (256 ideal) with the slice's own `ds_read` + `lgkmcnt(0)` between the
-    // step's first and second MFMA -- in-order issue held the chain behind the LDS round trip.
+    // Software pipeline inside the wave: block qb - 1's tile waits in the other accumulator and is filtered during block qb's chain.
+    // (History: the filter behind its own block's chain -- both waves of a SIMD in their MFMA phase, then both in their
+    // ~700-instruction filter phase with the matrix pipe idle: 0.68 of the pipe at D = 128; round 5: one (query, 32 rows) slice behind
+    // every 64 / NF-th of the chain with the next slice's LDS read a slice ahead: 0.70.)
     // Round 6 -- every instruction of a wave that is not an MFMA takes the matrix pipe away from that wave's chain for its issue
     // time (scripts/ubench/mfma_valu.hip: ~5 cycles per VALU instruction behind a dependent v_mfma_f32_32x32x2_f32, fully additive;
     // only the OTHER wave of the SIMD can fill the gap, and only with an MFMA of its own).  Rounds 5's per-slice filter spent ~16

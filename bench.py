@@ -50,6 +50,12 @@ Also in the line (N = 1, measured after the timed region):
   `encode_db_bvecs` (C2) and `encode_db_bvecs_qinco2S` -- the actual `task=encode` data path (search_tasks.py:85-137): a uint8 .bvecs file on disk ->
           get_data_memmap -> encode_database(QINCoHIP) -> part file, i.e. host buffers / PCIe included, next to the
           HBM-resident rate of the same model.
+  `small_db_search` -- f3 at bigann1M's shape: both forms of the brute-force top-100, bit-equality asserted on the line;
+  `roofline.traffic` (round 6) -- L2<->fabric bytes per launch of the dominant kernel, MEASURED for this run's command by two
+          rocprofv3 --pmc child passes (FETCH_SIZE x2, WRITE_SIZE) that run on the idle GPU while the CPU baseline is timed
+          (`--no-pmc`: fall back to the committed pass's bytes per row, and say so);
+  `rccl_world1`, `rccl_world1_ok` (round 6) -- `bench.py --gpus 1 --dry-rccl` as a child process: every RCCL step of the
+          multi-GPU bench on the real library with a communicator of ONE rank (`--no-rccl-check` skips it).
 cpu_baseline: the oracle restatement with its codeword MLP on torch CPU ops (oracle/qinco_oracle.py, backend "torch":
 same op sequence as the reference's CPU path, codes equal to the numpy oracle and to the imported reference) timed on
 this box's host cores at the reference's batch of 1024 on a bounded sample.
@@ -110,6 +116,9 @@ def pmc_traffic_live(args, kernel_substr: str = "mlp_kernel<") -> dict:
         return {"ok": False, "error": "rocprofv3 not found"}
     child = [sys.executable, str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--workload", args.workload, "--batch", str(args.batch),
              "--no-cpu-baseline", "--no-extras", "--no-legs", "--no-rccl-check", "--no-pmc", "--no-affinity"]
+    if getattr(args, "split_f16", False):
+        child.append("--split-f16")
+        kernel_substr = "mlp_split_kernel<"
     env = dict(os.environ, TMPDIR="/tmp")
     out = {"ok": True, "passes": {}}
     t0 = time.perf_counter()
